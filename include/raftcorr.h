@@ -1,0 +1,124 @@
+/* raftcorr.h -- C ABI of libraftcorr.so, the MI355X (gfx950) implementation of RAFT's
+ * correlation hot path.
+ *
+ * Every entry point takes raw device pointers, explicit sizes and a hipStream_t (passed as
+ * void*); nothing here depends on torch.  The library never allocates or frees device
+ * memory and keeps no reference to any buffer after a call returns: the caller owns all
+ * buffers (the Python host code allocates them through PyTorch's caching allocator).
+ * All kernels are launched asynchronously on the stream that is passed in.
+ *
+ * Return value: 0 on success, a negative RAFTCORR_E* code otherwise; the message for the
+ * calling thread's last failure is returned by raftcorr_last_error().
+ *
+ * The comments name the reference interface (damien911224/RAFT, paths relative to the
+ * repository root) that each entry point replaces.
+ */
+#ifndef RAFTCORR_H
+#define RAFTCORR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFTCORR_VERSION 1
+#define RAFTCORR_MAX_LEVELS 8
+
+#define RAFTCORR_OK            0
+#define RAFTCORR_EINVAL       (-1)   /* bad argument (null pointer, non-positive size, ...) */
+#define RAFTCORR_EUNSUPPORTED (-2)   /* valid request this build does not implement */
+#define RAFTCORR_ELAUNCH      (-3)   /* hipGetLastError() reported a launch failure */
+
+/* lookup conventions */
+#define RAFTCORR_MODE_FORK      0    /* core/corr.py:29-51 as shipped: coords (B,N,2) (x,y) level-0
+                                        pixels, SAME coords at every level, out (B,N,L*rd*rd) */
+#define RAFTCORR_MODE_CANONICAL 1    /* what core/raft.py:125 + core/update.py:82-91 consume and
+                                        core/corr.py:75-92 keeps: coords (B,2,H,W), coords/2**l per
+                                        level, out (B,L*rd*rd,H,W) */
+
+int raftcorr_version(void);
+const char* raftcorr_last_error(void);
+
+/* Host-only helper.  Level sizes of the pooled pyramid, H_l = floor(H_{l-1}/2)
+ * (F.avg_pool2d(corr, 2, stride=2), core/corr.py:25-27).  hl/wl: int32[num_levels]. */
+int raftcorr_level_dims(int H, int W, int num_levels, int32_t* hl, int32_t* wl);
+
+/* Replaces CorrBlock.__init__ + CorrBlock.corr (core/corr.py:13-27, :53-61):
+ *   level0[b,q,t] = <fmap1[b,:,q], fmap2[b,:,t]> / sqrt(D),  q,t in [0, H*W)
+ *   level l       = 2x2 mean of level l-1 over the target (h2,w2) dims, floor truncation.
+ * fmap1, fmap2: (B,D,H,W) float32 contiguous.  levels: HOST array of num_levels DEVICE pointers;
+ * levels[l] receives (B*H*W, 1, H_l, W_l) float32 contiguous (fully overwritten).
+ * One fused launch produces levels 0..3 (fp32 MFMA contraction, pooling in the epilogue);
+ * levels >= 4 are pooled from their predecessor by a second small kernel. */
+int raftcorr_build_pyramid(const float* fmap1, const float* fmap2,
+                           int B, int D, int H, int W, int num_levels,
+                           float* const* levels, void* stream);
+
+/* Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
+ * core/utils/utils.py:57-65): for every query q and level l the (2r+1)^2 window of 4-tap
+ * bilinear samples (zero padding) of levels[l][b*N+q] at (x + a - r, y + b - r); output channel
+ * l*rd*rd + a*rd + b (a = x offset = slow index).  mode selects the coordinate/ output
+ * convention (see RAFTCORR_MODE_*).  levels: HOST array of DEVICE pointers laid out as
+ * raftcorr_build_pyramid writes them.  out is fully overwritten. */
+int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels,
+                        int radius, const float* coords, int mode, float* out, void* stream);
+
+/* Backward of raftcorr_lookup_fwd (replaces grid_sampler_2d_backward reached through
+ * core/utils/utils.py:65).  dlevels[l] (same layout as levels, float32) is ACCUMULATED into
+ * (+=): zero it once, then call this for every lookup of the frame pair; no dense per-call
+ * gradient volume is created.  A (query, tap) cell is owned by exactly one thread, so no
+ * atomics are used and the result is deterministic.
+ * dcoords (nullable): gradient w.r.t. coords, same shape as coords, overwritten; needs levels.
+ * dlevels may be NULL when only dcoords is wanted (levels may be NULL when it is not). */
+int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels,
+                        int B, int H, int W, int num_levels, int radius,
+                        const float* coords, int mode, const float* dout,
+                        float* dcoords, void* stream);
+
+/* Backward of raftcorr_build_pyramid (replaces avg_pool2d_backward + the scale + bmm backward
+ * behind core/corr.py:26,59,61).  dlevels: accumulated pyramid gradient; level 0 is used as
+ * scratch and is CLOBBERED (it receives the folded level-0 gradient).
+ * dfmap1, dfmap2: (B,D,H,W) float32, overwritten. */
+int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+                       int num_levels, float* const* dlevels,
+                       float* dfmap1, float* dfmap2, void* stream);
+
+/* Drop-in for alt_cuda_corr.forward (alt_cuda_corr/correlation.cpp:23-33 ->
+ * correlation_kernel.cu:260-286): one level of on-the-fly correlation.
+ * fmap1 (B,H1,W1,C), fmap2 (B,H2,W2,C), coords (B,N,H1,W1,2) -> corr (B,N,rd*rd,H1,W1),
+ * all float32 contiguous; corr is fully overwritten and is NOT scaled by 1/sqrt(C). */
+int raftcorr_alt_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
+                         void* stream);
+
+/* Drop-in for alt_cuda_corr.backward (alt_cuda_corr/correlation.cpp:36-48 ->
+ * correlation_kernel.cu:288-324).  fmap1_grad (B,H1,W1,C), fmap2_grad (B,H2,W2,C) and
+ * coords_grad (B,N,H1,W1,2) are fully overwritten; coords_grad is all zeros, as in the
+ * reference (allocated at :307 and never written). coords_grad may be NULL. */
+int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* coords,
+                          const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
+                          float* coords_grad,
+                          int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
+                          void* stream);
+
+/* Replaces AlternateCorrBlock.__call__ (core/corr.py:75-92) in ONE launch: all levels, the
+ * per-level coords/2**l, the stack/reshape and the 1/sqrt(C) scale fused.
+ * fmap1 (B,H,W,C) NHWC; fmap2_levels: HOST array of DEVICE pointers, level l = avg-pooled
+ * fmap2 (B,H_l,W_l,C) NHWC; coords (B,2,H,W); out (B, L*rd*rd, H, W), overwritten. */
+int raftcorr_alt_lookup_fwd(const float* fmap1, const float* const* fmap2_levels,
+                            int B, int H, int W, int C, int num_levels, int radius,
+                            const float* coords, float* out, void* stream);
+
+/* Backward of raftcorr_alt_lookup_fwd.  dfmap1 (B,H,W,C) is overwritten (in-wave reduction,
+ * no atomics); dfmap2_levels[l] (B,H_l,W_l,C) must be zeroed by the caller and is accumulated
+ * with float atomics (targets collide across queries). */
+int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels,
+                            int B, int H, int W, int C, int num_levels, int radius,
+                            const float* coords, const float* dout,
+                            float* dfmap1, float* const* dfmap2_levels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTCORR_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libraftcorr.so (C ABI declared in include/raftcorr.h).
+
+The library is the only compute path: if it is missing or fails to load, importing
+:mod:`raft_amd.corr` symbols still works (so CPU-only hosts can inspect the API), but every
+operator raises ``RuntimeError`` -- there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraftcorr.so")
+
+MAX_LEVELS = 8
+MODE_FORK = 0
+MODE_CANONICAL = 1
+
+_c_fp = ctypes.c_void_p          # device pointers travel as plain addresses
+_c_int = ctypes.c_int
+
+# name -> argtypes; mirrors include/raftcorr.h one to one
+_SIGNATURES = {
+    "raftcorr_version": ([], _c_int),
+    "raftcorr_last_error": ([], ctypes.c_char_p),
+    "raftcorr_level_dims": ([_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int32),
+                             ctypes.POINTER(ctypes.c_int32)], _c_int),
+    "raftcorr_build_pyramid": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p], _c_int),
+    "raftcorr_lookup_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,
+                             _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_lookup_bwd": ([ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                             _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp,
+                             ctypes.c_void_p], _c_int),
+    "raftcorr_build_bwd": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                            ctypes.POINTER(ctypes.c_void_p), _c_fp, _c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_alt_forward": ([_c_fp, _c_fp, _c_fp, _c_fp] + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
+    "raftcorr_alt_backward": ([_c_fp] * 7 + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
+    "raftcorr_alt_lookup_fwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 6 +
+                                [_c_fp, _c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_alt_lookup_bwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 6 +
+                                [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
+                                _c_int),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+_load_error = None
+
+
+def load():
+    """Return the loaded library or raise RuntimeError (never falls back)."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is None:
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (argtypes, restype) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = restype
+            _lib = lib
+            return _lib
+        except (OSError, AttributeError) as e:      # missing file / missing symbol
+            _load_error = e
+    raise RuntimeError(
+        f"raft_amd: the HIP extension {LIB_PATH} is not available ({_load_error}); build it with "
+        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C raft_amd/csrc`. "
+        "There is no CPU fallback.")
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().raftcorr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"raftcorr {what} failed (code {rc}): {msg}")
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (None -> NULL)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None or t.numel() == 0 else t.data_ptr()
+    return arr
+
+
+def level_dims(H, W, num_levels):
+    """Pooled pyramid sizes, H_l = floor(H_{l-1} / 2) (pure host arithmetic; no library call so
+    that shape logic is testable without the extension)."""
+    dims = []
+    for _ in range(num_levels):
+        dims.append((H, W))
+        H //= 2
+        W //= 2
+    return dims

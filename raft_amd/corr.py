@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's correlation interface (core/corr.py), backed by
+libraftcorr.so (hand-written gfx950 kernels, C ABI in include/raftcorr.h).
+
+Same names, arguments and defaults as the reference:
+
+* ``CorrBlock(fmap1, fmap2, num_levels=2, radius=4)(coords)``       core/corr.py:12-61
+* ``CorrBlock.corr(fmap1, fmap2)``                                   core/corr.py:53-61
+* ``AlternateCorrBlock(fmap1, fmap2, num_levels=4, radius=4)(coords)`` core/corr.py:64-92
+* ``bilinear_sampler(img, coords)``                                  core/utils/utils.py:57-71
+
+``CorrBlock.__call__`` is bimodal: 3-D ``(B, N, 2)`` coords select the
+fork's semantics exactly as shipped (no per-level scaling, ``(B, N, C)`` output); 4-D
+``(B, 2, H, W)`` coords select the canonical RAFT semantics that core/raft.py:125 and
+core/update.py:82-91 consume (coords / 2**l per level, ``(B, C, H, W)`` output).
+
+Autograd: the reference differentiates through matmul / avg_pool2d / grid_sample and
+materialises a dense, zero-filled gradient of a whole pyramid level for EVERY lookup.  Here
+all lookups of one CorrBlock accumulate into ONE gradient pyramid that is folded into the
+feature gradients once, when autograd reaches the build node.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; there is no
+fallback path: without the HIP extension every operator raises RuntimeError.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+__all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler"]
+
+_ALIGN = 64   # level offsets inside the packed pyramid buffer, in elements (256 B)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(**tensors):
+    for name, t in tensors.items():
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")   # CHECK_CUDA, correlation.cpp:19
+
+
+def _f32c(t):
+    return t.float().contiguous()
+
+
+class _Pyramid:
+    """Packed pyramid storage + the shared gradient accumulator of one CorrBlock."""
+
+    def __init__(self, B, H, W, num_levels, device):
+        self.B, self.H, self.W, self.L = B, H, W, num_levels
+        self.N = H * W
+        self.dims = _lib.level_dims(H, W, num_levels)
+        self.offsets = []
+        off = 0
+        for (h, w) in self.dims:
+            self.offsets.append(off)
+            n = B * self.N * h * w
+            off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = max(off, 1)
+        self.device = device
+        self.flat = None          # detached storage of the volume levels
+        self.ptrs = None          # ctypes array of level pointers
+        self.dflat = None         # gradient accumulator (allocated on first lookup backward)
+        self.dptrs = None
+
+    def views(self, flat):
+        out = []
+        for (h, w), off in zip(self.dims, self.offsets):
+            out.append(flat[off:off + self.B * self.N * h * w].view(self.B * self.N, 1, h, w))
+        return out
+
+    def attach(self, flat):
+        self.flat = flat
+        self.ptrs = _lib.ptr_array(self.views(flat))
+
+    def grad_buffer(self):
+        if self.dflat is None:
+            self.dflat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            self.dptrs = _lib.ptr_array(self.views(self.dflat))
+        return self.dflat
+
+    def release_grad(self):
+        self.dflat = None
+        self.dptrs = None
+
+
+def _build(fmap1, fmap2, pyr):
+    lib = _lib.load()
+    B, D, H, W = fmap1.shape
+    flat = torch.empty(pyr.total, dtype=torch.float32, device=fmap1.device)
+    pyr.attach(flat)
+    with torch.cuda.device(fmap1.device):
+        _lib.check(lib.raftcorr_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
+                                              pyr.ptrs, _stream(fmap1)), "build_pyramid")
+    return flat
+
+
+class _BuildPyramid(torch.autograd.Function):
+    """fmap1, fmap2 -> (packed pyramid, anchor).  The anchor is a 1-element tensor that every
+    lookup takes as an input: it carries the graph edge lookups -> build without a dense
+    gradient per lookup (the lookups write into pyr.dflat and return a zero anchor gradient)."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, pyr):
+        flat = _build(fmap1, fmap2, pyr)
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.pyr = pyr
+        ctx.set_materialize_grads(False)
+        anchor = torch.zeros(1, dtype=torch.float32, device=fmap1.device)
+        return flat, anchor
+
+    @staticmethod
+    def backward(ctx, dflat, danchor):
+        fmap1, fmap2 = ctx.saved_tensors
+        pyr = ctx.pyr
+        if dflat is not None:                       # someone differentiated corr_pyramid directly
+            acc = pyr.grad_buffer()
+            acc += dflat
+        if pyr.dflat is None:
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
+        lib = _lib.load()
+        B, D, H, W = fmap1.shape
+        d1 = torch.empty_like(fmap1)
+        d2 = torch.empty_like(fmap2)
+        with torch.cuda.device(fmap1.device):
+            _lib.check(lib.raftcorr_build_bwd(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
+                                              pyr.dptrs, d1.data_ptr(), d2.data_ptr(), _stream(fmap1)),
+                       "build_bwd")
+        pyr.release_grad()                          # level 0 was clobbered by the fold
+        return d1, d2, None
+
+
+def _lookup(pyr, coords, radius, mode):
+    lib = _lib.load()
+    rd2 = (2 * radius + 1) ** 2
+    C = pyr.L * rd2
+    if mode == _lib.MODE_FORK:
+        out = torch.empty(pyr.B, pyr.N, C, dtype=torch.float32, device=coords.device)
+    else:
+        out = torch.empty(pyr.B, C, pyr.H, pyr.W, dtype=torch.float32, device=coords.device)
+    with torch.cuda.device(coords.device):
+        _lib.check(lib.raftcorr_lookup_fwd(pyr.ptrs, pyr.B, pyr.H, pyr.W, pyr.L, radius,
+                                           coords.data_ptr(), mode, out.data_ptr(), _stream(coords)),
+                   "lookup_fwd")
+    return out
+
+
+class _Lookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, coords, pyr, radius, mode):
+        ctx.pyr, ctx.radius, ctx.mode = pyr, radius, mode
+        ctx.save_for_backward(coords)
+        return _lookup(pyr, coords, radius, mode)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        pyr = ctx.pyr
+        lib = _lib.load()
+        dout = _f32c(dout)
+        need_vol = ctx.needs_input_grad[0]
+        need_co = ctx.needs_input_grad[1]
+        dcoords = torch.empty_like(coords) if need_co else None
+        with torch.cuda.device(coords.device):
+            dptrs = None
+            if need_vol:
+                pyr.grad_buffer()
+                dptrs = pyr.dptrs
+            _lib.check(lib.raftcorr_lookup_bwd(pyr.ptrs, dptrs, pyr.B, pyr.H, pyr.W, pyr.L, ctx.radius,
+                                               coords.data_ptr(), ctx.mode, dout.data_ptr(),
+                                               dcoords.data_ptr() if need_co else None,
+                                               _stream(coords)), "lookup_bwd")
+        danchor = torch.zeros(1, dtype=torch.float32, device=coords.device) if need_vol else None
+        return danchor, dcoords, None, None, None
+
+
+class CorrBlock:
+    """All-pairs correlation volume + pooled pyramid + radius-r bilinear lookup.
+    Drop-in for core/corr.py:12-61 (same constructor defaults: num_levels=2, radius=4)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=2, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        _require_cuda(fmap1=fmap1, fmap2=fmap2)
+        if fmap1.dim() != 4 or fmap1.shape != fmap2.shape:
+            raise RuntimeError(f"CorrBlock: fmap1/fmap2 must both be (B, D, H, W); got "
+                               f"{tuple(fmap1.shape)} and {tuple(fmap2.shape)}")
+        if not 1 <= num_levels <= _lib.MAX_LEVELS:
+            raise RuntimeError(f"CorrBlock: num_levels must be in [1, {_lib.MAX_LEVELS}]")
+        if radius < 0:
+            raise RuntimeError("CorrBlock: radius must be >= 0")
+        fmap1, fmap2 = _f32c(fmap1), _f32c(fmap2)
+        B, D, H, W = fmap1.shape
+        self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device)
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr)
+            self._pyr.flat = flat.detach()
+        else:
+            flat = _build(fmap1, fmap2, self._pyr)
+            self._anchor = None
+        # list of (B*H*W, 1, H_l, W_l) tensors, as core/corr.py:16-27 exposes it
+        self.corr_pyramid = self._pyr.views(flat)
+
+    def __call__(self, coords):
+        _require_cuda(coords=coords)
+        p = self._pyr
+        if coords.dim() == 3:                                   # fork semantics, core/corr.py:29-51
+            mode = _lib.MODE_FORK
+            if coords.shape != (p.B, p.N, 2):
+                raise RuntimeError(f"CorrBlock: coords must be ({p.B}, {p.N}, 2); got {tuple(coords.shape)}")
+        elif coords.dim() == 4:                                 # canonical RAFT, core/raft.py:125
+            mode = _lib.MODE_CANONICAL
+            if coords.shape != (p.B, 2, p.H, p.W):
+                raise RuntimeError(f"CorrBlock: coords must be ({p.B}, 2, {p.H}, {p.W}); got {tuple(coords.shape)}")
+        else:
+            raise RuntimeError("CorrBlock: coords must be (B, N, 2) or (B, 2, H, W)")
+        coords = _f32c(coords)
+        track = torch.is_grad_enabled() and (self._anchor is not None or coords.requires_grad)
+        if not track:
+            return _lookup(p, coords, self.radius, mode)
+        anchor = self._anchor if self._anchor is not None else \
+            torch.zeros(1, dtype=torch.float32, device=coords.device)
+        return _Lookup.apply(anchor, coords, p, self.radius, mode)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """core/corr.py:53-61: (B, D, H, W) x2 -> (B, H, W, 1, H, W), already divided by sqrt(D)."""
+        B, D, H, W = fmap1.shape
+        blk = CorrBlock(fmap1, fmap2, num_levels=1, radius=0)
+        return blk.corr_pyramid[0].view(B, H, W, 1, H, W)
+
+
+def bilinear_sampler(img, coords, mode='bilinear', mask=False):
+    """core/utils/utils.py:57-71, same signature and semantics (pixel coords -> grid_sample with
+    align_corners=True, zero padding).  Kept for callers that import it from the corr module's
+    neighbourhood; CorrBlock itself does NOT use it -- the window lookup is fused into
+    raftcorr_lookup_fwd.  General sampling grids are outside the hot path (stock torch op)."""
+    H, W = img.shape[-2:]
+    xgrid, ygrid = coords.split([1, 1], dim=-1)
+    xgrid = 2 * xgrid / (W - 1) - 1
+    ygrid = 2 * ygrid / (H - 1) - 1
+    grid = torch.cat([xgrid, ygrid], dim=-1)
+    img = F.grid_sample(img, grid, align_corners=True)
+    if mask:
+        m = (xgrid > -1) & (ygrid > -1) & (xgrid < 1) & (ygrid < 1)
+        return img, m.float()
+    return img
+
+
+class _AltLookup(torch.autograd.Function):
+    """All levels of the on-the-fly correlation in one launch (forward) / one launch (backward)."""
+
+    @staticmethod
+    def forward(ctx, coords, radius, fmap1, *fmap2_levels):
+        lib = _lib.load()
+        B, H, W, C = fmap1.shape
+        L = len(fmap2_levels)
+        rd2 = (2 * radius + 1) ** 2
+        out = torch.empty(B, L * rd2, H, W, dtype=torch.float32, device=fmap1.device)
+        with torch.cuda.device(fmap1.device):
+            _lib.check(lib.raftcorr_alt_lookup_fwd(fmap1.data_ptr(), _lib.ptr_array(fmap2_levels), B, H, W,
+                                                   C, L, radius, coords.data_ptr(), out.data_ptr(),
+                                                   _stream(fmap1)), "alt_lookup_fwd")
+        ctx.radius = radius
+        ctx.save_for_backward(coords, fmap1, *fmap2_levels)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        coords, fmap1, *levels = ctx.saved_tensors
+        B, H, W, C = fmap1.shape
+        L = len(levels)
+        dout = _f32c(dout)
+        d1 = torch.empty_like(fmap1)
+        d2 = [torch.zeros_like(t) for t in levels]
+        with torch.cuda.device(fmap1.device):
+            _lib.check(lib.raftcorr_alt_lookup_bwd(fmap1.data_ptr(), _lib.ptr_array(levels), B, H, W, C, L,
+                                                   ctx.radius, coords.data_ptr(), dout.data_ptr(),
+                                                   d1.data_ptr(), _lib.ptr_array(d2), _stream(fmap1)),
+                       "alt_lookup_bwd")
+        # coords gradient: the reference kernel never writes it (correlation_kernel.cu:307)
+        return (None, None, d1, *d2)
+
+
+class AlternateCorrBlock:
+    """Memory-lean on-the-fly correlation.  Drop-in for core/corr.py:64-92 (defaults
+    num_levels=4, radius=4); unlike the reference it is differentiable w.r.t. the features."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        _require_cuda(fmap1=fmap1, fmap2=fmap2)
+        if not 1 <= num_levels <= _lib.MAX_LEVELS:
+            raise RuntimeError(f"AlternateCorrBlock: num_levels must be in [1, {_lib.MAX_LEVELS}]")
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+        self.pyramid = [(fmap1, fmap2)]                        # core/corr.py:69-73 (L+1 entries)
+        for _ in range(self.num_levels):
+            fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
+            fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
+            self.pyramid.append((fmap1, fmap2))
+        # NHWC copies made once here (the reference re-makes them on every call, corr.py:83-84)
+        self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
+        self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+
+    def __call__(self, coords):
+        _require_cuda(coords=coords)
+        B, H, W, C = self._f1.shape
+        if coords.shape != (B, 2, H, W):
+            raise RuntimeError(f"AlternateCorrBlock: coords must be ({B}, 2, {H}, {W}); got {tuple(coords.shape)}")
+        return _AltLookup.apply(_f32c(coords).detach(), self.radius, self._f1, *self._f2)

@@ -1,0 +1,207 @@
+// extern "C" surface of libraftcorr.so: argument validation, error text, dispatch.
+// Declarations and the reference interface each entry point replaces: include/raftcorr.h.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace raftcorr {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return RAFTCORR_OK;
+}
+
+static void level_dims(int H, int W, int L, int* hl, int* wl)
+{
+    for (int l = 0; l < L; ++l) { hl[l] = H; wl[l] = W; H /= 2; W /= 2; }
+}
+
+// levels: host array of device pointers -> by-value LevelSet with the pooled sizes
+static int make_levels(const char* who, const float* const* ptrs, int H, int W, int L, LevelSet& lv,
+                       bool allow_null = false)
+{
+    if (L < 1 || L > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "%s: num_levels = %d not in [1, %d]", who, L, RAFTCORR_MAX_LEVELS);
+    if (!ptrs) return fail(RAFTCORR_EINVAL, "%s: null level pointer array", who);
+    int hl[RAFTCORR_MAX_LEVELS], wl[RAFTCORR_MAX_LEVELS];
+    level_dims(H, W, L, hl, wl);
+    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.h[l] = 0; lv.w[l] = 0; }
+    for (int l = 0; l < L; ++l) {
+        lv.h[l] = hl[l]; lv.w[l] = wl[l];
+        lv.ptr[l] = const_cast<float*>(ptrs[l]);
+        if (!ptrs[l] && !allow_null && hl[l] > 0 && wl[l] > 0)
+            return fail(RAFTCORR_EINVAL, "%s: level %d pointer is null", who, l);
+    }
+    return RAFTCORR_OK;
+}
+
+static int check_dims(const char* who, int B, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1) return fail(RAFTCORR_EINVAL, "%s: B, H, W must be positive (got %d, %d, %d)", who, B, H, W);
+    if (B > 65535) return fail(RAFTCORR_EUNSUPPORTED, "%s: B = %d > 65535", who, B);
+    if ((long long)H * W > (1LL << 24)) return fail(RAFTCORR_EUNSUPPORTED, "%s: H*W = %lld too large", who, (long long)H * W);
+    return RAFTCORR_OK;
+}
+
+}  // namespace raftcorr
+
+using namespace raftcorr;
+
+extern "C" {
+
+int raftcorr_version(void) { return RAFTCORR_VERSION; }
+
+const char* raftcorr_last_error(void) { return g_err; }
+
+int raftcorr_level_dims(int H, int W, int num_levels, int32_t* hl, int32_t* wl)
+{
+    if (H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || !hl || !wl)
+        return fail(RAFTCORR_EINVAL, "level_dims: bad argument");
+    level_dims(H, W, num_levels, hl, wl);
+    return RAFTCORR_OK;
+}
+
+int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+                           int num_levels, float* const* levels, void* stream)
+{
+    int rc = check_dims("build_pyramid", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2) return fail(RAFTCORR_EINVAL, "build_pyramid: null feature map");
+    if (D < 1) return fail(RAFTCORR_EINVAL, "build_pyramid: D = %d", D);
+    LevelSet lv;
+    rc = make_levels("build_pyramid", levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_build_pyramid(fmap1, fmap2, B, D, H, W, num_levels, lv, (hipStream_t)stream);
+}
+
+int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels, int radius,
+                        const float* coords, int mode, float* out, void* stream)
+{
+    int rc = check_dims("lookup_fwd", B, H, W);
+    if (rc) return rc;
+    if (!coords || !out) return fail(RAFTCORR_EINVAL, "lookup_fwd: null coords/out");
+    if (radius < 0) return fail(RAFTCORR_EINVAL, "lookup_fwd: radius = %d", radius);
+    if (mode != RAFTCORR_MODE_FORK && mode != RAFTCORR_MODE_CANONICAL)
+        return fail(RAFTCORR_EINVAL, "lookup_fwd: mode = %d", mode);
+    LevelSet lv;
+    rc = make_levels("lookup_fwd", levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_lookup_fwd(lv, B, H, W, num_levels, radius, coords, mode, out, (hipStream_t)stream);
+}
+
+int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels, int B, int H, int W,
+                        int num_levels, int radius, const float* coords, int mode, const float* dout,
+                        float* dcoords, void* stream)
+{
+    int rc = check_dims("lookup_bwd", B, H, W);
+    if (rc) return rc;
+    if (!coords || !dout) return fail(RAFTCORR_EINVAL, "lookup_bwd: null coords/dout");
+    if (radius < 0) return fail(RAFTCORR_EINVAL, "lookup_bwd: radius = %d", radius);
+    if (mode != RAFTCORR_MODE_FORK && mode != RAFTCORR_MODE_CANONICAL)
+        return fail(RAFTCORR_EINVAL, "lookup_bwd: mode = %d", mode);
+    LevelSet lv, dlv;
+    const bool have = levels != nullptr, have_d = dlevels != nullptr;
+    if (!have_d && !dcoords) return fail(RAFTCORR_EINVAL, "lookup_bwd: neither dlevels nor dcoords given");
+    if (dcoords && !have) return fail(RAFTCORR_EINVAL, "lookup_bwd: dcoords needs levels");
+    if (have_d) {
+        rc = make_levels("lookup_bwd(dlevels)", dlevels, H, W, num_levels, dlv);
+        if (rc) return rc;
+    }
+    if (have) {
+        rc = make_levels("lookup_bwd(levels)", levels, H, W, num_levels, lv);
+        if (rc) return rc;
+    }
+    if (!have) lv = dlv;
+    if (!have_d) { dlv = lv; for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) dlv.ptr[l] = nullptr; }
+    return launch_lookup_bwd(lv, dlv, have_d, B, H, W, num_levels, radius, coords, mode, dout, dcoords,
+                             (hipStream_t)stream);
+}
+
+int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+                       int num_levels, float* const* dlevels, float* dfmap1, float* dfmap2, void* stream)
+{
+    int rc = check_dims("build_bwd", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !dfmap1 || !dfmap2) return fail(RAFTCORR_EINVAL, "build_bwd: null pointer");
+    if (D < 1) return fail(RAFTCORR_EINVAL, "build_bwd: D = %d", D);
+    LevelSet dlv;
+    rc = make_levels("build_bwd", dlevels, H, W, num_levels, dlv);
+    if (rc) return rc;
+    return launch_build_bwd(fmap1, fmap2, B, D, H, W, num_levels, dlv, dfmap1, dfmap2, (hipStream_t)stream);
+}
+
+static int alt_level_check(const char* who, int B, int N, int H1, int W1, int H2, int W2, int C, int r)
+{
+    int rc = check_dims(who, B, H1, W1);
+    if (rc) return rc;
+    if (N < 1 || H2 < 1 || W2 < 1 || C < 1 || r < 0)
+        return fail(RAFTCORR_EINVAL, "%s: bad size (N=%d H2=%d W2=%d C=%d r=%d)", who, N, H2, W2, C, r);
+    if ((long long)B * N > 65535) return fail(RAFTCORR_EUNSUPPORTED, "%s: B*N > 65535", who);
+    return RAFTCORR_OK;
+}
+
+int raftcorr_alt_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream)
+{
+    int rc = alt_level_check("alt_forward", B, N, H1, W1, H2, W2, C, radius);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !coords || !corr) return fail(RAFTCORR_EINVAL, "alt_forward: null pointer");
+    return launch_alt_level_fwd(fmap1, fmap2, coords, corr, B, N, H1, W1, H2, W2, C, radius, (hipStream_t)stream);
+}
+
+int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* coords,
+                          const float* corr_grad, float* fmap1_grad, float* fmap2_grad, float* coords_grad,
+                          int B, int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream)
+{
+    int rc = alt_level_check("alt_backward", B, N, H1, W1, H2, W2, C, radius);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !coords || !corr_grad || !fmap1_grad || !fmap2_grad)
+        return fail(RAFTCORR_EINVAL, "alt_backward: null pointer");
+    return launch_alt_level_bwd(fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, coords_grad,
+                                B, N, H1, W1, H2, W2, C, radius, (hipStream_t)stream);
+}
+
+int raftcorr_alt_lookup_fwd(const float* fmap1, const float* const* fmap2_levels, int B, int H, int W,
+                            int C, int num_levels, int radius, const float* coords, float* out, void* stream)
+{
+    int rc = check_dims("alt_lookup_fwd", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !coords || !out) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: null pointer");
+    if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: C=%d radius=%d", C, radius);
+    LevelSet lv;
+    rc = make_levels("alt_lookup_fwd", fmap2_levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_alt_lookup_fwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, out, (hipStream_t)stream);
+}
+
+int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels, int B, int H, int W,
+                            int C, int num_levels, int radius, const float* coords, const float* dout,
+                            float* dfmap1, float* const* dfmap2_levels, void* stream)
+{
+    int rc = check_dims("alt_lookup_bwd", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !coords || !dout || !dfmap1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: null pointer");
+    if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: C=%d radius=%d", C, radius);
+    LevelSet lv, dlv;
+    rc = make_levels("alt_lookup_bwd(fmap2)", fmap2_levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    rc = make_levels("alt_lookup_bwd(dfmap2)", dfmap2_levels, H, W, num_levels, dlv);
+    if (rc) return rc;
+    return launch_alt_lookup_bwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, dout, dfmap1, dlv,
+                                 (hipStream_t)stream);
+}
+
+}  // extern "C"

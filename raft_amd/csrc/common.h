@@ -1,0 +1,49 @@
+// Internal declarations shared by the kernel files of libraftcorr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/raftcorr.h"
+
+namespace raftcorr {
+
+// thread-local error text behind raftcorr_last_error()
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+struct LevelSet {                 // by-value kernel argument: per-level pointers and sizes
+    float* ptr[RAFTCORR_MAX_LEVELS];
+    int h[RAFTCORR_MAX_LEVELS];
+    int w[RAFTCORR_MAX_LEVELS];
+};
+
+// launchers (each validates nothing: the extern "C" layer in api.hip does)
+int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
+                         const LevelSet& lv, hipStream_t s);
+int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
+                      int mode, float* out, hipStream_t s);
+int launch_lookup_bwd(const LevelSet& lv, const LevelSet& dlv, bool have_dlevels, int B, int H, int W,
+                      int L, int r, const float* coords, int mode, const float* dout,
+                      float* dcoords, hipStream_t s);
+int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
+                     const LevelSet& dlv, float* df1, float* df2, hipStream_t s);
+int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, float* corr,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
+int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,
+                         float* g1, float* g2, float* gc,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
+int launch_alt_lookup_fwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
+                          int r, const float* coords, float* out, hipStream_t s);
+int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
+                          int r, const float* coords, const float* dout, float* df1,
+                          const LevelSet& df2lv, hipStream_t s);
+
+// floor + fraction of a sampling coordinate, memory-safe for NaN / huge values: anything
+// that is not a sane pixel coordinate is pushed far outside the map (all taps read as zero).
+__device__ __forceinline__ void split_coord(float x, int& x0, float& fx) {
+    if (!(x > -1.0e6f && x < 1.0e6f)) { x0 = -(1 << 24); fx = 0.f; return; }
+    float f = floorf(x);
+    x0 = (int)f;
+    fx = x - f;
+}
+
+}  // namespace raftcorr

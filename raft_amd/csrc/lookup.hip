@@ -1,0 +1,298 @@
+// Radius-r bilinear window lookup over the correlation pyramid, forward and backward.
+//
+// Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
+// core/utils/utils.py:57-65): per level ~10 tiny launches (linspace, meshgrid, stack, add,
+// split, 2 affine maps, cat, grid_sample, view) plus a final cat/contiguous copy.  Here every
+// level of every query is produced by one launch.
+//
+// All (2r+1)^2 samples of one (query, level) share the same fractional offsets, so they
+// are a 2x2 box filter over the (2r+2)^2 integer taps around floor(coords):
+//   out(a, b) = w00*T[b][a] + w01*T[b][a+1] + w10*T[b+1][a] + w11*T[b+1][a+1]
+// with a = x offset (slow output index), b = y offset (fast), T[ty][tx] the volume entry at
+// (y0 - r + ty, x0 - r + tx) or 0 outside the level (grid_sample's zero padding).
+//
+// A block handles QB = 32 consecutive queries of one level:
+//   phase 0  32 threads split the coordinates (floor / fraction)          -> LDS
+//   phase 1  all threads gather the 32 x (2r+2)^2 taps, row segments of
+//            2r+2 contiguous floats per query                             -> LDS
+//   phase 2  all threads blend 4 LDS taps per output and store coalesced: along the
+//            channel dim for the (B,N,C) layout, along the query dim for (B,C,H,W).
+// The backward pass mirrors it: dOut tile -> LDS, each tap's gradient is the 2x2 box
+// filter of dOut, added to d(level) with a plain read-modify-write: a (query, tap) cell
+// belongs to exactly one thread of one block, so no atomics are needed.
+#include "common.h"
+
+namespace raftcorr {
+
+constexpr int QB = 32;
+
+struct LookupArgs {
+    LevelSet lv;        // volume levels (fwd: read; bwd: read for dcoords only)
+    LevelSet dlv;       // bwd: gradient levels, accumulated
+    const float* coords;
+    const float* dout;  // bwd
+    float* out;         // fwd
+    float* dcoords;     // bwd, optional
+    int B, N, L, r;
+    int mode;           // RAFTCORR_MODE_*
+};
+
+__device__ __forceinline__ void load_xy(const LookupArgs& p, int b, int q, int l, float& x, float& y)
+{
+    if (p.mode == RAFTCORR_MODE_FORK) {
+        const float* c = p.coords + ((size_t)b * p.N + q) * 2;
+        x = c[0]; y = c[1];
+    } else {
+        const float* c = p.coords + (size_t)b * 2 * p.N + q;
+        const float s = 1.0f / (float)(1 << l);          // exact power of two == coords / 2**l
+        x = c[0] * s; y = c[p.N] * s;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256)
+void corr_lookup_fwd_kernel(LookupArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = (R >= 0) ? R : p.r;
+    const int T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
+    const int ST = TT | 1;                       // odd stride: conflict-free query-major reads
+    float* taps = smem;                          // [QB][ST]
+    float* sfx = smem + QB * ST;                 // [QB]
+    float* sfy = sfx + QB;
+    int* sx0 = (int*)(sfy + QB);
+    int* sy0 = sx0 + QB;
+
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB;
+    const int tid = threadIdx.x;
+    const int Hl = p.lv.h[l], Wl = p.lv.w[l];
+    const float* __restrict__ vol = p.lv.ptr[l];
+    const int N = p.N;
+
+    if (tid < QB) {
+        const int q = q0 + tid;
+        float x = 0.f, y = 0.f;
+        if (q < N) load_xy(p, b, q, l, x, y);
+        int x0, y0; float fx, fy;
+        split_coord(x, x0, fx);
+        split_coord(y, y0, fy);
+        sx0[tid] = x0 - r; sy0[tid] = y0 - r; sfx[tid] = fx; sfy[tid] = fy;
+    }
+    __syncthreads();
+
+    for (int e = tid; e < QB * TT; e += 256) {
+        const int qi = e / TT;
+        const int t = e - qi * TT;
+        const int ty = t / T;
+        const int tx = t - ty * T;
+        const int q = q0 + qi;
+        const int xi = sx0[qi] + tx, yi = sy0[qi] + ty;
+        float v = 0.f;
+        if (q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)
+            v = vol[(((size_t)b * N + q) * Hl + yi) * Wl + xi];
+        taps[qi * ST + t] = v;
+    }
+    __syncthreads();
+
+    const int C = p.L * rd2;
+    if (p.mode == RAFTCORR_MODE_FORK) {
+        // out (B, N, C): lanes run along the channel dim
+        float* __restrict__ out = p.out + ((size_t)b * N + q0) * C + l * rd2;
+        for (int e = tid; e < QB * rd2; e += 256) {
+            const int qi = e / rd2;
+            const int ch = e - qi * rd2;
+            const int a = ch / rd;
+            const int bb = ch - a * rd;
+            if (q0 + qi >= N) break;
+            const float fx = sfx[qi], fy = sfy[qi];
+            const float* tp = taps + qi * ST + bb * T + a;
+            const float o = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
+                            tp[T] * ((1.f - fx) * fy) + tp[T + 1] * (fx * fy);
+            out[(size_t)qi * C + ch] = o;
+        }
+    } else {
+        // out (B, C, N): lanes run along the query dim
+        float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
+        const int qi = tid & (QB - 1);
+        const bool vq = q0 + qi < N;
+        const float fx = sfx[qi], fy = sfy[qi];
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
+        const float w10 = (1.f - fx) * fy, w11 = fx * fy;
+        for (int ch = tid / QB; ch < rd2; ch += 256 / QB) {
+            const int a = ch / rd;
+            const int bb = ch - a * rd;
+            const float* tp = taps + qi * ST + bb * T + a;
+            const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
+            if (vq) out[(size_t)ch * N + qi] = o;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256)
+void corr_lookup_bwd_kernel(LookupArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = (R >= 0) ? R : p.r;
+    const int T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
+    const int SG = rd2 | 1;
+    float* g = smem;                             // [QB][SG]  dOut tile
+    float* sfx = smem + QB * SG;
+    float* sfy = sfx + QB;
+    int* sx0 = (int*)(sfy + QB);
+    int* sy0 = sx0 + QB;
+
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB;
+    const int tid = threadIdx.x;
+    const int Hl = p.dlv.h[l], Wl = p.dlv.w[l];
+    float* __restrict__ dvol = p.dlv.ptr[l];
+    const int N = p.N;
+    const int C = p.L * rd2;
+
+    if (tid < QB) {
+        const int q = q0 + tid;
+        float x = 0.f, y = 0.f;
+        if (q < N) load_xy(p, b, q, l, x, y);
+        int x0, y0; float fx, fy;
+        split_coord(x, x0, fx);
+        split_coord(y, y0, fy);
+        sx0[tid] = x0 - r; sy0[tid] = y0 - r; sfx[tid] = fx; sfy[tid] = fy;
+    }
+    if (p.mode == RAFTCORR_MODE_FORK) {
+        const float* __restrict__ d = p.dout + ((size_t)b * N + q0) * C + l * rd2;
+        for (int e = tid; e < QB * rd2; e += 256) {
+            const int qi = e / rd2;
+            const int ch = e - qi * rd2;
+            g[qi * SG + ch] = (q0 + qi < N) ? d[(size_t)qi * C + ch] : 0.f;
+        }
+    } else {
+        const float* __restrict__ d = p.dout + ((size_t)b * C + l * rd2) * N + q0;
+        const int qi = tid & (QB - 1);
+        const bool vq = q0 + qi < N;
+        for (int ch = tid / QB; ch < rd2; ch += 256 / QB)
+            g[qi * SG + ch] = vq ? d[(size_t)ch * N + qi] : 0.f;
+    }
+    __syncthreads();
+
+    for (int e = tid; e < QB * TT; e += 256) {
+        const int qi = e / TT;
+        const int t = e - qi * TT;
+        const int ty = t / T;
+        const int tx = t - ty * T;
+        const int q = q0 + qi;
+        const int xi = sx0[qi] + tx, yi = sy0[qi] + ty;
+        if (!(q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)) continue;
+        const float fx = sfx[qi], fy = sfy[qi];
+        const float* gq = g + qi * SG;           // channel = a*rd + b, a <-> x, b <-> y
+        float acc = 0.f;
+        if (tx < rd && ty < rd) acc += gq[tx * rd + ty] * ((1.f - fx) * (1.f - fy));
+        if (tx > 0 && ty < rd)  acc += gq[(tx - 1) * rd + ty] * (fx * (1.f - fy));
+        if (tx < rd && ty > 0)  acc += gq[tx * rd + ty - 1] * ((1.f - fx) * fy);
+        if (tx > 0 && ty > 0)   acc += gq[(tx - 1) * rd + ty - 1] * (fx * fy);
+        float* dst = dvol + (((size_t)b * N + q) * Hl + yi) * Wl + xi;
+        *dst += acc;
+    }
+}
+
+// d(out)/d(coords): one block = 32 queries, all levels; 8 lanes per query reduce by shuffles.
+__global__ __launch_bounds__(256)
+void corr_lookup_dcoords_kernel(LookupArgs p)
+{
+    const int r = p.r, T = 2 * r + 2, rd = 2 * r + 1, rd2 = rd * rd;
+    const int b = blockIdx.z;
+    const int q = blockIdx.x * QB + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    const int N = p.N, C = p.L * rd2;
+    (void)T;
+    float gx = 0.f, gy = 0.f;
+    if (q < N) {
+        for (int l = 0; l < p.L; ++l) {
+            const int Hl = p.lv.h[l], Wl = p.lv.w[l];
+            const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q) * Hl * Wl;
+            float x, y;
+            load_xy(p, b, q, l, x, y);
+            int x0, y0; float fx, fy;
+            split_coord(x, x0, fx);
+            split_coord(y, y0, fy);
+            float sx = 0.f, sy = 0.f;
+            for (int ch = sub; ch < rd2; ch += 8) {
+                const int a = ch / rd, bb = ch - a * rd;
+                const int xi = x0 - r + a, yi = y0 - r + bb;
+                auto tap = [&](int yy, int xx) -> float {
+                    return (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl) ? vol[(size_t)yy * Wl + xx] : 0.f;
+                };
+                const float t00 = tap(yi, xi), t01 = tap(yi, xi + 1);
+                const float t10 = tap(yi + 1, xi), t11 = tap(yi + 1, xi + 1);
+                const float d = (p.mode == RAFTCORR_MODE_FORK)
+                                    ? p.dout[((size_t)b * N + q) * C + l * rd2 + ch]
+                                    : p.dout[((size_t)b * C + l * rd2 + ch) * N + q];
+                sx += d * ((1.f - fy) * (t01 - t00) + fy * (t11 - t10));
+                sy += d * ((1.f - fx) * (t10 - t00) + fx * (t11 - t01));
+            }
+            const float s = (p.mode == RAFTCORR_MODE_FORK) ? 1.f : 1.0f / (float)(1 << l);
+            gx += sx * s; gy += sy * s;
+        }
+    }
+    for (int m = 1; m < 8; m <<= 1) { gx += __shfl_xor(gx, m); gy += __shfl_xor(gy, m); }
+    if (q < N && sub == 0) {
+        if (p.mode == RAFTCORR_MODE_FORK) {
+            float* c = p.dcoords + ((size_t)b * N + q) * 2;
+            c[0] = gx; c[1] = gy;
+        } else {
+            float* c = p.dcoords + (size_t)b * 2 * N + q;
+            c[0] = gx; c[N] = gy;
+        }
+    }
+}
+
+static size_t lookup_smem(int r, bool bwd)
+{
+    const int T = 2 * r + 2, rd = 2 * r + 1;
+    const int stride = bwd ? ((rd * rd) | 1) : ((T * T) | 1);
+    return sizeof(float) * ((size_t)QB * stride + 4 * QB);
+}
+
+int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
+                      int mode, float* out, hipStream_t s)
+{
+    LookupArgs a = {};
+    a.lv = lv; a.coords = coords; a.out = out;
+    a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = mode;
+    const size_t sm = lookup_smem(r, false);
+    if (sm > 64 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_fwd: radius %d too large", r);
+    dim3 grid((a.N + QB - 1) / QB, L, B), block(256);
+    if (r == 4)      hipLaunchKernelGGL(corr_lookup_fwd_kernel<4>, grid, block, sm, s, a);
+    else if (r == 3) hipLaunchKernelGGL(corr_lookup_fwd_kernel<3>, grid, block, sm, s, a);
+    else             hipLaunchKernelGGL(corr_lookup_fwd_kernel<-1>, grid, block, sm, s, a);
+    return check_launch("corr_lookup_fwd_kernel");
+}
+
+int launch_lookup_bwd(const LevelSet& lv, const LevelSet& dlv, bool have_dlevels, int B, int H, int W,
+                      int L, int r, const float* coords, int mode, const float* dout,
+                      float* dcoords, hipStream_t s)
+{
+    LookupArgs a = {};
+    a.lv = lv; a.dlv = dlv; a.coords = coords; a.dout = dout; a.dcoords = dcoords;
+    a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = mode;
+    dim3 grid((a.N + QB - 1) / QB, L, B), block(256);
+    int rc = RAFTCORR_OK;
+    if (have_dlevels) {
+        const size_t sm = lookup_smem(r, true);
+        if (sm > 64 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_bwd: radius %d too large", r);
+        if (r == 4)      hipLaunchKernelGGL(corr_lookup_bwd_kernel<4>, grid, block, sm, s, a);
+        else if (r == 3) hipLaunchKernelGGL(corr_lookup_bwd_kernel<3>, grid, block, sm, s, a);
+        else             hipLaunchKernelGGL(corr_lookup_bwd_kernel<-1>, grid, block, sm, s, a);
+        rc = check_launch("corr_lookup_bwd_kernel");
+        if (rc) return rc;
+    }
+    if (dcoords) {
+        dim3 g2((a.N + QB - 1) / QB, 1, B);
+        hipLaunchKernelGGL(corr_lookup_dcoords_kernel, g2, block, 0, s, a);
+        rc = check_launch("corr_lookup_dcoords_kernel");
+    }
+    return rc;
+}
+
+}  // namespace raftcorr

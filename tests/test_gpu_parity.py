@@ -1,0 +1,283 @@
+"""GPU parity: the HIP path (through the Python host -> ctypes -> C ABI of libraftcorr.so)
+against the golden vectors recorded from the reference and against the CPU oracle.
+
+Bar (BASELINE.json north_star): <= 1e-5 relative in fp32, where relative = max|a-b| / max|b|
+(conftest.rel_err).  Gradients are sums of thousands of fp32 products in a different order
+than the CPU's, so they get 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+GTOL = 2e-5
+FORK = ["F1_fork_fwd", "F2_fork_bwd", "F3_fork_defaults", "F4_fork_edges"]
+CANON = ["C1_canon_fwd_a", "C1_canon_fwd_b", "C2_canon_bwd"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from raft_amd import _lib
+    _lib.load()                                   # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, grad=False):
+    return torch.from_numpy(np.array(a)).to(dev).requires_grad_(grad)
+
+
+@pytest.mark.parametrize("name", FORK + CANON)
+def test_golden_forward_backward(name, dev):
+    from raft_amd import CorrBlock
+    g = load_golden(name)
+    L, r = int(g["num_levels"]), int(g["radius"])
+    grad = "gout" in g
+    f1, f2, co = _t(g["fmap1"], dev, grad), _t(g["fmap2"], dev, grad), _t(g["coords"], dev, grad)
+    cb = CorrBlock(f1, f2, num_levels=L, radius=r)
+    out = cb(co)
+    assert out.shape == g["out"].shape and out.dtype == torch.float32 and out.is_contiguous()
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    if grad:
+        out.backward(_t(g["gout"], dev))
+        assert rel_err(f1.grad.cpu().numpy(), g["dfmap1"]) <= GTOL
+        assert rel_err(f2.grad.cpu().numpy(), g["dfmap2"]) <= GTOL
+        assert rel_err(co.grad.cpu().numpy(), g["dcoords"]) <= 5e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 55, 128), (1, 256, 47, 156), (2, 128, 27, 64),
+                                   (1, 40, 13, 32), (3, 7, 9, 21), (1, 256, 50, 90)])
+def test_pyramid_matches_oracle(shape, dev):
+    """All-pairs build + fused pooled levels at the BASELINE shapes and odd sizes."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    B, D, H, W = shape
+    rs = np.random.RandomState(B * 1000 + D + H + W)
+    f1 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    f2 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    L = 4 if min(H, W) >= 16 else 3
+    ref = O.build_pyramid_torch(f1, f2, L)
+    cb = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=4)
+    assert len(cb.corr_pyramid) == L
+    for l in range(L):
+        assert cb.corr_pyramid[l].shape == ref[l].shape
+        assert rel_err(cb.corr_pyramid[l].cpu().numpy(), ref[l].numpy()) <= TOL, f"level {l}"
+    c = CorrBlock.corr(f1.to(dev), f2.to(dev))
+    assert c.shape == (B, H, W, 1, H, W)
+    assert rel_err(c.cpu().numpy(), O.all_pairs_corr_torch(f1, f2).numpy()) <= TOL
+
+
+def test_more_than_four_levels(dev):
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(3)
+    f1 = torch.from_numpy(rs.randn(1, 16, 40, 72).astype(np.float32))
+    f2 = torch.from_numpy(rs.randn(1, 16, 40, 72).astype(np.float32))
+    ref = O.build_pyramid_torch(f1, f2, 5)
+    cb = CorrBlock(f1.to(dev), f2.to(dev), num_levels=5, radius=2)
+    for l in range(5):
+        assert rel_err(cb.corr_pyramid[l].cpu().numpy(), ref[l].numpy()) <= TOL
+    co = torch.from_numpy((rs.rand(1, 40 * 72, 2) * [71, 39]).astype(np.float32))
+    assert rel_err(cb(co.to(dev)).cpu().numpy(), O.lookup_fork_torch(ref, co, 2).numpy()) <= TOL
+
+
+def _sintel_inputs():
+    g = load_golden("S1_sintel")
+    B, D, H, W = (int(v) for v in g["shape"])
+    rs = np.random.RandomState(1234)
+    f1 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    f2 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].astype(np.float32)
+    co4 = torch.from_numpy((base + 3.0 * rs.randn(B, 2, H, W)).astype(np.float32))
+    co3 = co4.permute(0, 2, 3, 1).reshape(B, H * W, 2).contiguous()
+    return g, f1, f2, co3, co4
+
+
+def test_sintel_shape_against_reference_checksums(dev):
+    """S1: the benchmark configuration itself (D=256, 55x128, 4 levels, r=4) against rows,
+    slabs and checksums recorded from the reference."""
+    from raft_amd import CorrBlock
+    g, f1, f2, co3, co4 = _sintel_inputs()
+    H, W = f1.shape[-2:]
+    L, r = int(g["num_levels"]), int(g["radius"])
+    cb = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r)
+    for l in range(L):
+        p = cb.corr_pyramid[l]
+        assert abs(p.double().abs().sum().item() - g["level_abs"][l]) <= 1e-5 * g["level_abs"][l]
+        assert rel_err(p[torch.from_numpy(g["vrows"]).to(dev), 0].cpu().numpy(), g[f"slab_l{l}"]) <= TOL
+    rows = g["rows"]
+    of = cb(co3.to(dev))
+    assert rel_err(of[0, rows].cpu().numpy(), g["out_fork_rows"]) <= TOL
+    oc = cb(co4.to(dev))
+    assert rel_err(oc[0].reshape(-1, H * W)[:, rows].T.cpu().numpy(), g["out_canon_rows"]) <= TOL
+    scale = float(np.abs(g["out_fork_rows"]).mean()) * of.numel()
+    assert abs(of.double().sum().item() - float(g["out_fork_sum"])) <= 1e-5 * scale
+    assert abs(oc.double().sum().item() - float(g["out_canon_sum"])) <= 1e-5 * scale
+
+
+def test_full_size_properties(dev):
+    """Size-independent properties at the full Sintel shape: linearity of the volume in fmap1,
+    integer coordinates pick volume entries exactly, lookups are deterministic, and the
+    canonical and fork conventions agree where they must (level 0)."""
+    from raft_amd import CorrBlock
+    _, f1, f2, co3, co4 = _sintel_inputs()
+    f1, f2, co3, co4 = f1.to(dev), f2.to(dev), co3.to(dev), co4.to(dev)
+    B, D, H, W = f1.shape
+    N = H * W
+    cb = CorrBlock(f1, f2, num_levels=4, radius=4)
+    cb2 = CorrBlock(2.0 * f1, f2, num_levels=4, radius=4)
+    for l in range(4):                                            # exact: scaling by 2 is exact
+        assert torch.equal(cb2.corr_pyramid[l], 2.0 * cb.corr_pyramid[l])
+    a, b = cb(co3), cb(co3)
+    assert torch.equal(a, b)
+    # level 0 of both conventions is the same sampling problem
+    oc = cb(co4).reshape(B, 4, 81, N)[:, 0].permute(0, 2, 1)
+    assert rel_err(oc.cpu().numpy(), a[:, :, :81].cpu().numpy()) <= 1e-6
+    # integer coordinates: out[q, a*9+b] = vol[q, y+b-4, x+a-4] (0 outside)
+    xs = torch.randint(0, W, (B, N), device=dev)
+    ys = torch.randint(0, H, (B, N), device=dev)
+    out = cb(torch.stack([xs, ys], -1).float())[:, :, :81].reshape(B, N, 9, 9)
+    vol = cb.corr_pyramid[0].view(B, N, H, W)
+    pad = torch.nn.functional.pad(vol, (4, 4, 4, 4))
+    q = torch.arange(N, device=dev)
+    for (aa, bb) in [(0, 0), (4, 4), (8, 8), (2, 7), (7, 1)]:
+        exp = pad[0, q, ys[0] + bb, xs[0] + aa]
+        assert torch.equal(out[0, :, aa, bb], exp)
+
+
+def test_lookup_backward_accumulates_across_iterations(dev):
+    """12 lookups, one shared gradient pyramid: equals the oracle's autograd over the same graph."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(21)
+    B, D, H, W, L, r, iters = 2, 32, 16, 24, 4, 4, 12
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].repeat(B, 0).astype(np.float32)
+    coords = [base + (k + 1) * 0.7 * rs.randn(B, 2, H, W).astype(np.float32) for k in range(iters)]
+    gouts = [rs.randn(B, L * 81, H, W).astype(np.float32) for _ in range(iters)]
+
+    def run(make, device):
+        f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+        cb = make(f1, f2)
+        loss = 0
+        for c, g in zip(coords, gouts):
+            loss = loss + (cb(torch.from_numpy(c).to(device)) * torch.from_numpy(g).to(device)).sum()
+        loss.backward()
+        return f1.grad.cpu().numpy(), f2.grad.cpu().numpy()
+
+    g1, g2 = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r), dev)
+    o1, o2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu")
+    assert rel_err(g1, o1) <= GTOL and rel_err(g2, o2) <= GTOL
+
+
+def test_pyramid_tensors_are_differentiable(dev):
+    """corr_pyramid entries carry autograd like the reference's (core/corr.py:24-27)."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(8)
+    f1n, f2n = rs.randn(1, 8, 10, 12).astype(np.float32), rs.randn(1, 8, 10, 12).astype(np.float32)
+    w = [rs.randn(120, 1, 10 >> l, 12 >> l).astype(np.float32) for l in range(3)]
+
+    def run(make, device):
+        f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+        pyr = make(f1, f2)
+        sum((p * torch.from_numpy(wl).to(device)).sum() for p, wl in zip(pyr, w)).backward()
+        return f1.grad.cpu().numpy(), f2.grad.cpu().numpy()
+
+    g1, g2 = run(lambda a, b: CorrBlock(a, b, num_levels=3).corr_pyramid, dev)
+    o1, o2 = run(lambda a, b: O.build_pyramid_torch(a, b, 3), "cpu")
+    assert rel_err(g1, o1) <= GTOL and rel_err(g2, o2) <= GTOL
+
+
+# ---------------------------------------------------------------------------------------
+# on-the-fly ("alternate") path
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [(2, 1, 11, 16, 11, 16, 64, 4), (1, 2, 9, 13, 5, 7, 32, 3),
+                                  (1, 1, 6, 7, 6, 7, 30, 2), (1, 1, 8, 8, 4, 4, 256, 4)])
+def test_alt_cuda_corr_dropin_matches_c_oracle(case, dev):
+    """raft_amd.alt_cuda_corr.forward/backward (the pybind surface of correlation.cpp:51-54)
+    against the C restatement of the CUDA kernels."""
+    from raft_amd import alt_cuda_corr
+    from oracle import alt_corr_c
+    B, N, H1, W1, H2, W2, C, r = case
+    rs = np.random.RandomState(sum(case))
+    f1 = rs.randn(B, H1, W1, C).astype(np.float32)
+    f2 = rs.randn(B, H2, W2, C).astype(np.float32)
+    co = (rs.rand(B, N, H1, W1, 2) * [W2 + 4, H2 + 4] - 2).astype(np.float32)
+    co[0, 0, 0, 0] = [3.0, 2.0]                                    # exactly integer
+    cg = rs.randn(B, N, (2 * r + 1) ** 2, H1, W1).astype(np.float32)
+    ref, = alt_corr_c.forward(f1, f2, co, r)
+    r1, r2, rc = alt_corr_c.backward(f1, f2, co, cg, r)
+    tf1, tf2, tco, tcg = (torch.from_numpy(a).to(dev) for a in (f1, f2, co, cg))
+    out, = alt_cuda_corr.forward(tf1, tf2, tco, r)
+    assert out.shape == ref.shape
+    assert rel_err(out.cpu().numpy(), ref) <= TOL
+    g1, g2, gc = alt_cuda_corr.backward(tf1, tf2, tco, tcg, r)
+    assert rel_err(g1.cpu().numpy(), r1) <= GTOL
+    assert rel_err(g2.cpu().numpy(), r2) <= GTOL
+    assert gc.shape == tco.shape and not gc.any().item()
+
+
+def test_alt_cuda_corr_error_behaviour(dev):
+    from raft_amd import alt_cuda_corr
+    f = torch.zeros(1, 4, 4, 8, device=dev)
+    co = torch.zeros(1, 1, 4, 4, 2, device=dev)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        alt_cuda_corr.forward(f.cpu(), f, co, 1)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        alt_cuda_corr.forward(f.permute(0, 2, 1, 3), f, co, 1)
+
+
+@pytest.mark.parametrize("name", CANON)
+def test_alternate_corr_block_matches_canonical_reference(name, dev):
+    """A1: AlternateCorrBlock == canonical all-pairs lookup of the reference (golden C1/C2)."""
+    from raft_amd import AlternateCorrBlock
+    g = load_golden(name)
+    L, r = int(g["num_levels"]), int(g["radius"])
+    grad = "gout" in g
+    f1, f2, co = _t(g["fmap1"], dev, grad), _t(g["fmap2"], dev, grad), _t(g["coords"], dev)
+    blk = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)
+    assert len(blk.pyramid) == L + 1
+    out = blk(co)
+    assert out.shape == g["out"].shape
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    if grad:
+        out.backward(_t(g["gout"], dev))
+        assert rel_err(f1.grad.cpu().numpy(), g["dfmap1"]) <= GTOL
+        assert rel_err(f2.grad.cpu().numpy(), g["dfmap2"]) <= GTOL
+
+
+def test_alt_equals_all_pairs_at_kitti_shape(dev):
+    """Config 3 shape (47x156, D=256): both of our paths agree with each other."""
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    rs = np.random.RandomState(47)
+    B, D, H, W = 1, 256, 47, 156
+    f1 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32)).to(dev)
+    f2 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32)).to(dev)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    co = np.stack([xx, yy], 0)[None].astype(np.float32) + 4.0 * rs.randn(B, 2, H, W).astype(np.float32)
+    co = torch.from_numpy(co).to(dev)
+    a = AlternateCorrBlock(f1, f2, num_levels=4, radius=4)(co)
+    b = CorrBlock(f1, f2, num_levels=4, radius=4)(co)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL
+
+
+def test_host_errors(dev):
+    from raft_amd import CorrBlock
+    f = torch.zeros(1, 8, 6, 6, device=dev)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        CorrBlock(f.cpu(), f)
+    cb = CorrBlock(f, f)
+    assert cb.num_levels == 2 and cb.radius == 4              # reference defaults, corr.py:13
+    with pytest.raises(RuntimeError):
+        cb(torch.zeros(1, 35, 2, device=dev))
+    with pytest.raises(RuntimeError):
+        cb(torch.zeros(1, 2, 6, 5, device=dev))
