@@ -31,8 +31,19 @@ __all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler"]
 _ALIGN = 64   # level offsets inside the packed pyramid buffer, in elements (256 B)
 
 
+import contextlib
+
+_NULL = contextlib.nullcontext()
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _guard(t):
+    """Device guard only when the tensor does not live on the current device (the context
+    manager costs more host time than a lookup kernel runs)."""
+    return _NULL if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
 
 
 def _require_cuda(**tensors):
@@ -91,7 +102,7 @@ def _build(fmap1, fmap2, pyr):
     B, D, H, W = fmap1.shape
     flat = torch.empty(pyr.total, dtype=torch.float32, device=fmap1.device)
     pyr.attach(flat)
-    with torch.cuda.device(fmap1.device):
+    with _guard(fmap1):
         _lib.check(lib.raftcorr_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
                                               pyr.ptrs, _stream(fmap1)), "build_pyramid")
     return flat
@@ -124,7 +135,7 @@ class _BuildPyramid(torch.autograd.Function):
         B, D, H, W = fmap1.shape
         d1 = torch.empty_like(fmap1)
         d2 = torch.empty_like(fmap2)
-        with torch.cuda.device(fmap1.device):
+        with _guard(fmap1):
             _lib.check(lib.raftcorr_build_bwd(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
                                               pyr.dptrs, d1.data_ptr(), d2.data_ptr(), _stream(fmap1)),
                        "build_bwd")
@@ -140,7 +151,7 @@ def _lookup(pyr, coords, radius, mode):
         out = torch.empty(pyr.B, pyr.N, C, dtype=torch.float32, device=coords.device)
     else:
         out = torch.empty(pyr.B, C, pyr.H, pyr.W, dtype=torch.float32, device=coords.device)
-    with torch.cuda.device(coords.device):
+    with _guard(coords):
         _lib.check(lib.raftcorr_lookup_fwd(pyr.ptrs, pyr.B, pyr.H, pyr.W, pyr.L, radius,
                                            coords.data_ptr(), mode, out.data_ptr(), _stream(coords)),
                    "lookup_fwd")
@@ -163,7 +174,7 @@ class _Lookup(torch.autograd.Function):
         need_vol = ctx.needs_input_grad[0]
         need_co = ctx.needs_input_grad[1]
         dcoords = torch.empty_like(coords) if need_co else None
-        with torch.cuda.device(coords.device):
+        with _guard(coords):
             dptrs = None
             if need_vol:
                 pyr.grad_buffer()
@@ -259,7 +270,7 @@ class _AltLookup(torch.autograd.Function):
         L = len(fmap2_levels)
         rd2 = (2 * radius + 1) ** 2
         out = torch.empty(B, L * rd2, H, W, dtype=torch.float32, device=fmap1.device)
-        with torch.cuda.device(fmap1.device):
+        with _guard(fmap1):
             _lib.check(lib.raftcorr_alt_lookup_fwd(fmap1.data_ptr(), _lib.ptr_array(fmap2_levels), B, H, W,
                                                    C, L, radius, coords.data_ptr(), out.data_ptr(),
                                                    _stream(fmap1)), "alt_lookup_fwd")
@@ -276,7 +287,7 @@ class _AltLookup(torch.autograd.Function):
         dout = _f32c(dout)
         d1 = torch.empty_like(fmap1)
         d2 = [torch.zeros_like(t) for t in levels]
-        with torch.cuda.device(fmap1.device):
+        with _guard(fmap1):
             _lib.check(lib.raftcorr_alt_lookup_bwd(fmap1.data_ptr(), _lib.ptr_array(levels), B, H, W, C, L,
                                                    ctx.radius, coords.data_ptr(), dout.data_ptr(),
                                                    d1.data_ptr(), _lib.ptr_array(d2), _stream(fmap1)),
