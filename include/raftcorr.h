@@ -40,27 +40,46 @@ extern "C" {
 int raftcorr_version(void);
 const char* raftcorr_last_error(void);
 
-/* Host-only helper.  Level sizes of the pooled pyramid, H_l = floor(H_{l-1}/2)
- * (F.avg_pool2d(corr, 2, stride=2), core/corr.py:25-27).  hl/wl: int32[num_levels]. */
-int raftcorr_level_dims(int H, int W, int num_levels, int32_t* hl, int32_t* wl);
+/* ---- pyramid memory layout -------------------------------------------------------------
+ * Level l of the pyramid is a (B*H*W) x slab[l] float32 matrix: one SLAB of slab[l] elements per
+ * query pixel (row q of the all-pairs matrix), holding that query's H_l x W_l correlation map
+ * with the target pixels in "patch-tile order" (8x16 patches of four 4x8 tiles; one tile = one
+ * 128-byte line; raft_amd/csrc/layout.h), padded at the far edges.  The order is what lets a
+ * lookup window touch few cache lines and the build kernel pool in registers; callers that
+ * want the reference's (B*H*W, 1, H_l, W_l) tensors (core/corr.py:24-27) gather them with
+ * raftcorr_level_positions (the Python host does, lazily, for CorrBlock.corr_pyramid). */
+
+/* Host-only.  Logical level sizes H_l = floor(H_{l-1}/2) (F.avg_pool2d(corr, 2, stride=2),
+ * core/corr.py:25-27) and slab sizes in elements.  hl, wl: int32[num_levels]; slab: int64[num_levels]. */
+int raftcorr_level_layout(int H, int W, int num_levels, int32_t* hl, int32_t* wl, int64_t* slab);
+
+/* Host-only.  pos[y*W_l + x] = offset of logical cell (y, x) of level `level` inside a slab.
+ * pos: int32[H_l * W_l]. */
+int raftcorr_level_positions(int H, int W, int level, int32_t* pos);
+
+/* Host-only.  Scratch bytes raftcorr_build_pyramid / raftcorr_build_bwd need (caller-allocated
+ * device memory; contents are don't-care before and after the call). */
+int64_t raftcorr_build_workspace_bytes(int B, int D, int H, int W);
+int64_t raftcorr_build_bwd_workspace_bytes(int B, int D, int H, int W);
 
 /* Replaces CorrBlock.__init__ + CorrBlock.corr (core/corr.py:13-27, :53-61):
  *   level0[b,q,t] = <fmap1[b,:,q], fmap2[b,:,t]> / sqrt(D),  q,t in [0, H*W)
  *   level l       = 2x2 mean of level l-1 over the target (h2,w2) dims, floor truncation.
  * fmap1, fmap2: (B,D,H,W) float32 contiguous.  levels: HOST array of num_levels DEVICE pointers;
- * levels[l] receives (B*H*W, 1, H_l, W_l) float32 contiguous (fully overwritten).
- * One fused launch produces levels 0..3 (fp32 MFMA contraction, pooling in the epilogue);
- * levels >= 4 are pooled from their predecessor by a second small kernel. */
+ * levels[l] receives B*H*W slabs of slab[l] floats (fully overwritten, padding included).
+ * A small pack pass + one fused launch produce levels 0..3 (fp32 MFMA contraction, pooling in
+ * the epilogue); levels >= 4 are pooled from their predecessor by a further small kernel. */
 int raftcorr_build_pyramid(const float* fmap1, const float* fmap2,
                            int B, int D, int H, int W, int num_levels,
-                           float* const* levels, void* stream);
+                           float* const* levels, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 /* Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
  * core/utils/utils.py:57-65): for every query q and level l the (2r+1)^2 window of 4-tap
  * bilinear samples (zero padding) of levels[l][b*N+q] at (x + a - r, y + b - r); output channel
  * l*rd*rd + a*rd + b (a = x offset = slow index).  mode selects the coordinate/ output
  * convention (see RAFTCORR_MODE_*).  levels: HOST array of DEVICE pointers laid out as
- * raftcorr_build_pyramid writes them.  out is fully overwritten. */
+ * raftcorr_build_pyramid writes them (slabs in patch-tile order).  out is fully overwritten. */
 int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels,
                         int radius, const float* coords, int mode, float* out, void* stream);
 
@@ -77,12 +96,14 @@ int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels,
                         float* dcoords, void* stream);
 
 /* Backward of raftcorr_build_pyramid (replaces avg_pool2d_backward + the scale + bmm backward
- * behind core/corr.py:26,59,61).  dlevels: accumulated pyramid gradient; level 0 is used as
- * scratch and is CLOBBERED (it receives the folded level-0 gradient).
+ * behind core/corr.py:26,59,61).  dlevels: accumulated pyramid gradient (padding cells must be
+ * zero: zero the buffers once, lookups never touch padding); level 0 is used as scratch and is
+ * CLOBBERED (it receives the folded level-0 gradient); levels 3.. are clobbered when L > 4.
  * dfmap1, dfmap2: (B,D,H,W) float32, overwritten. */
 int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
                        int num_levels, float* const* dlevels,
-                       float* dfmap1, float* dfmap2, void* stream);
+                       float* dfmap1, float* dfmap2, void* workspace, int64_t workspace_bytes,
+                       void* stream);
 
 /* Drop-in for alt_cuda_corr.forward (alt_cuda_corr/correlation.cpp:23-33 ->
  * correlation_kernel.cu:260-286): one level of on-the-fly correlation.

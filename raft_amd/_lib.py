@@ -21,17 +21,22 @@ _c_int = ctypes.c_int
 _SIGNATURES = {
     "raftcorr_version": ([], _c_int),
     "raftcorr_last_error": ([], ctypes.c_char_p),
-    "raftcorr_level_dims": ([_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int32),
-                             ctypes.POINTER(ctypes.c_int32)], _c_int),
+    "raftcorr_level_layout": ([_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int32),
+                               ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)], _c_int),
+    "raftcorr_level_positions": ([_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int32)], _c_int),
+    "raftcorr_build_workspace_bytes": ([_c_int] * 4, ctypes.c_int64),
+    "raftcorr_build_bwd_workspace_bytes": ([_c_int] * 4, ctypes.c_int64),
     "raftcorr_build_pyramid": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p], _c_int),
+                                ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
+                                ctypes.c_void_p], _c_int),
     "raftcorr_lookup_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),
     "raftcorr_lookup_bwd": ([ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                              _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp,
                              ctypes.c_void_p], _c_int),
     "raftcorr_build_bwd": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
-                            ctypes.POINTER(ctypes.c_void_p), _c_fp, _c_fp, ctypes.c_void_p], _c_int),
+                            ctypes.POINTER(ctypes.c_void_p), _c_fp, _c_fp, _c_fp, ctypes.c_int64,
+                            ctypes.c_void_p], _c_int),
     "raftcorr_alt_forward": ([_c_fp, _c_fp, _c_fp, _c_fp] + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
     "raftcorr_alt_backward": ([_c_fp] * 7 + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_fwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 6 +
@@ -84,11 +89,34 @@ def ptr_array(tensors):
 
 
 def level_dims(H, W, num_levels):
-    """Pooled pyramid sizes, H_l = floor(H_{l-1} / 2) (pure host arithmetic; no library call so
-    that shape logic is testable without the extension)."""
+    """Logical pooled sizes, H_l = floor(H_{l-1} / 2) (pure host arithmetic, no library call)."""
     dims = []
     for _ in range(num_levels):
         dims.append((H, W))
         H //= 2
         W //= 2
     return dims
+
+
+def level_layout(H, W, num_levels):
+    """[(H_l, W_l, slab_l)] from the library (the layout's single source of truth)."""
+    hl = (ctypes.c_int32 * num_levels)()
+    wl = (ctypes.c_int32 * num_levels)()
+    sl = (ctypes.c_int64 * num_levels)()
+    check(load().raftcorr_level_layout(H, W, num_levels, hl, wl, sl), "level_layout")
+    return [(hl[i], wl[i], sl[i]) for i in range(num_levels)]
+
+
+_pos_cache = {}
+
+
+def level_positions(H, W, level):
+    """numpy int64 array (H_l*W_l,) of slab offsets of the logical cells of a level (cached)."""
+    import numpy as np
+    key = (H, W, level)
+    if key not in _pos_cache:
+        h, w = H >> level, W >> level
+        buf = (ctypes.c_int32 * max(h * w, 1))()
+        check(load().raftcorr_level_positions(H, W, level, buf), "level_positions")
+        _pos_cache[key] = np.frombuffer(buf, dtype=np.int32, count=h * w).astype(np.int64)
+    return _pos_cache[key]

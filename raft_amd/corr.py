@@ -57,39 +57,49 @@ def _f32c(t):
 
 
 class _Pyramid:
-    """Packed pyramid storage + the shared gradient accumulator of one CorrBlock."""
+    """Packed pyramid storage (patch-tile order, include/raftcorr.h) + the shared gradient
+    accumulator of one CorrBlock."""
 
     def __init__(self, B, H, W, num_levels, device):
         self.B, self.H, self.W, self.L = B, H, W, num_levels
         self.N = H * W
-        self.dims = _lib.level_dims(H, W, num_levels)
+        self.layout = _lib.level_layout(H, W, num_levels)       # [(H_l, W_l, slab_l)]
         self.offsets = []
         off = 0
-        for (h, w) in self.dims:
+        for (_, _, slab) in self.layout:
             self.offsets.append(off)
-            n = B * self.N * h * w
-            off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            off += (B * self.N * slab + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = max(off, 1)
         self.device = device
         self.flat = None          # detached storage of the volume levels
         self.ptrs = None          # ctypes array of level pointers
         self.dflat = None         # gradient accumulator (allocated on first lookup backward)
         self.dptrs = None
+        self._index = {}
 
-    def views(self, flat):
+    def slabs(self, flat):
+        """Per level: (B*N, slab_l) view of the packed buffer (device layout)."""
+        return [flat[off:off + self.B * self.N * slab].view(self.B * self.N, slab)
+                for (_, _, slab), off in zip(self.layout, self.offsets)]
+
+    def logical(self, flat):
+        """Per level: the reference's (B*N, 1, H_l, W_l) tensor (core/corr.py:22-27), gathered out
+        of the patch-tile order with differentiable stock indexing (off the hot path)."""
         out = []
-        for (h, w), off in zip(self.dims, self.offsets):
-            out.append(flat[off:off + self.B * self.N * h * w].view(self.B * self.N, 1, h, w))
+        for l, ((h, w, _), s) in enumerate(zip(self.layout, self.slabs(flat))):
+            if l not in self._index:
+                self._index[l] = torch.from_numpy(_lib.level_positions(self.H, self.W, l)).to(self.device)
+            out.append(s.index_select(1, self._index[l]).view(self.B * self.N, 1, h, w))
         return out
 
     def attach(self, flat):
         self.flat = flat
-        self.ptrs = _lib.ptr_array(self.views(flat))
+        self.ptrs = _lib.ptr_array(self.slabs(flat))
 
     def grad_buffer(self):
         if self.dflat is None:
             self.dflat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-            self.dptrs = _lib.ptr_array(self.views(self.dflat))
+            self.dptrs = _lib.ptr_array(self.slabs(self.dflat))
         return self.dflat
 
     def release_grad(self):
@@ -102,9 +112,12 @@ def _build(fmap1, fmap2, pyr):
     B, D, H, W = fmap1.shape
     flat = torch.empty(pyr.total, dtype=torch.float32, device=fmap1.device)
     pyr.attach(flat)
+    wbytes = lib.raftcorr_build_workspace_bytes(B, D, H, W)
+    work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
     with _guard(fmap1):
         _lib.check(lib.raftcorr_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
-                                              pyr.ptrs, _stream(fmap1)), "build_pyramid")
+                                              pyr.ptrs, work.data_ptr(), wbytes, _stream(fmap1)),
+                   "build_pyramid")
     return flat
 
 
@@ -135,10 +148,12 @@ class _BuildPyramid(torch.autograd.Function):
         B, D, H, W = fmap1.shape
         d1 = torch.empty_like(fmap1)
         d2 = torch.empty_like(fmap2)
+        wbytes = lib.raftcorr_build_bwd_workspace_bytes(B, D, H, W)
+        work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
         with _guard(fmap1):
             _lib.check(lib.raftcorr_build_bwd(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
-                                              pyr.dptrs, d1.data_ptr(), d2.data_ptr(), _stream(fmap1)),
-                       "build_bwd")
+                                              pyr.dptrs, d1.data_ptr(), d2.data_ptr(), work.data_ptr(),
+                                              wbytes, _stream(fmap1)), "build_bwd")
         pyr.release_grad()                          # level 0 was clobbered by the fold
         return d1, d2, None
 
@@ -211,8 +226,16 @@ class CorrBlock:
         else:
             flat = _build(fmap1, fmap2, self._pyr)
             self._anchor = None
-        # list of (B*H*W, 1, H_l, W_l) tensors, as core/corr.py:16-27 exposes it
-        self.corr_pyramid = self._pyr.views(flat)
+        self._flat = flat            # packed levels (autograd-tracked when the features are)
+        self._logical = None
+
+    @property
+    def corr_pyramid(self):
+        """List of (B*H*W, 1, H_l, W_l) tensors, as core/corr.py:16-27 exposes it.  The kernels
+        keep the levels in patch-tile order; this view is gathered on first access only."""
+        if self._logical is None:
+            self._logical = self._pyr.logical(self._flat)
+        return self._logical
 
     def __call__(self, coords):
         _require_cuda(coords=coords)

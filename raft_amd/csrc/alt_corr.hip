@@ -66,7 +66,7 @@ void alt_corr_fwd_kernel(AltArgs p)
     const int q0 = blockIdx.x * AQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = p.C, P = p.P;
-    const int Hl = p.f2.h[l], Wl = p.f2.w[l];
+    const int Hl = p.f2.g[l].h, Wl = p.f2.g[l].w;
     const float* __restrict__ f2 = p.f2.ptr[l] + (size_t)b * Hl * Wl * C;
     const bool vec = (C & 3) == 0;
     const int nch = (C + 255) / 256;
@@ -186,7 +186,7 @@ void alt_corr_bwd_kernel(AltArgs p)
         }
         for (int n = 0; n < p.Nc; ++n)
         for (int l = 0; l < p.L; ++l) {
-            const int Hl = p.f2.h[l], Wl = p.f2.w[l];
+            const int Hl = p.f2.g[l].h, Wl = p.f2.g[l].w;
             const float* __restrict__ f2 = p.f2.ptr[l] + (size_t)b * Hl * Wl * C;
             float* __restrict__ d2 = p.df2.ptr[l] + (size_t)b * Hl * Wl * C;
             float x, y;
@@ -289,7 +289,7 @@ int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, 
     int rc = alt_check(C, r, "alt_forward");
     if (rc) return rc;
     AltArgs a = {};
-    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.h[0] = H2; a.f2.w[0] = W2;
+    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.g[0].h = H2; a.f2.g[0].w = W2;
     a.coords = coords; a.out = corr;
     a.B = B; a.Nc = N; a.P = H1 * W1; a.C = C; a.L = 1; a.r = r;
     a.planar = 0; a.level_scale = 0; a.out_div = 1.0f;
@@ -306,8 +306,8 @@ int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, 
     if (e == hipSuccess && gc) e = hipMemsetAsync(gc, 0, sizeof(float) * (size_t)B * N * H1 * W1 * 2, s);
     if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_backward: memset: %s", hipGetErrorString(e));
     AltArgs a = {};
-    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.h[0] = H2; a.f2.w[0] = W2;
-    a.df2.ptr[0] = g2; a.df2.h[0] = H2; a.df2.w[0] = W2;
+    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.g[0].h = H2; a.f2.g[0].w = W2;
+    a.df2.ptr[0] = g2; a.df2.g[0].h = H2; a.df2.g[0].w = W2;
     a.coords = coords; a.dout = cg; a.df1 = g1;
     a.B = B; a.Nc = N; a.P = H1 * W1; a.C = C; a.L = 1; a.r = r;
     a.planar = 0; a.level_scale = 0; a.out_div = 1.0f;

@@ -24,25 +24,21 @@ int check_launch(const char* what)
     return RAFTCORR_OK;
 }
 
-static void level_dims(int H, int W, int L, int* hl, int* wl)
-{
-    for (int l = 0; l < L; ++l) { hl[l] = H; wl[l] = W; H /= 2; W /= 2; }
-}
-
-// levels: host array of device pointers -> by-value LevelSet with the pooled sizes
+// levels: host array of device pointers -> by-value LevelSet.  volume = true: pyramid levels in the
+// patch-tile order of layout.h; false: plain (h, w) feature-map levels (on-the-fly path).
 static int make_levels(const char* who, const float* const* ptrs, int H, int W, int L, LevelSet& lv,
-                       bool allow_null = false)
+                       bool volume = true)
 {
     if (L < 1 || L > RAFTCORR_MAX_LEVELS)
         return fail(RAFTCORR_EINVAL, "%s: num_levels = %d not in [1, %d]", who, L, RAFTCORR_MAX_LEVELS);
     if (!ptrs) return fail(RAFTCORR_EINVAL, "%s: null level pointer array", who);
-    int hl[RAFTCORR_MAX_LEVELS], wl[RAFTCORR_MAX_LEVELS];
-    level_dims(H, W, L, hl, wl);
-    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.h[l] = 0; lv.w[l] = 0; }
+    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.g[l] = LevelGeom{0, 0, 0, 4, 0}; }
     for (int l = 0; l < L; ++l) {
-        lv.h[l] = hl[l]; lv.w[l] = wl[l];
+        if (volume) lv.g[l] = level_geom(H, W, l);
+        else { lv.g[l].h = H >> l; lv.g[l].w = W >> l; lv.g[l].pw = 0; lv.g[l].kind = 4;
+               lv.g[l].slab = (int64_t)(H >> l) * (W >> l); }
         lv.ptr[l] = const_cast<float*>(ptrs[l]);
-        if (!ptrs[l] && !allow_null && hl[l] > 0 && wl[l] > 0)
+        if (!ptrs[l] && lv.g[l].h > 0 && lv.g[l].w > 0)
             return fail(RAFTCORR_EINVAL, "%s: level %d pointer is null", who, l);
     }
     return RAFTCORR_OK;
@@ -66,16 +62,42 @@ int raftcorr_version(void) { return RAFTCORR_VERSION; }
 
 const char* raftcorr_last_error(void) { return g_err; }
 
-int raftcorr_level_dims(int H, int W, int num_levels, int32_t* hl, int32_t* wl)
+int raftcorr_level_layout(int H, int W, int num_levels, int32_t* hl, int32_t* wl, int64_t* slab)
 {
-    if (H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || !hl || !wl)
-        return fail(RAFTCORR_EINVAL, "level_dims: bad argument");
-    level_dims(H, W, num_levels, hl, wl);
+    if (H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || !hl || !wl || !slab)
+        return fail(RAFTCORR_EINVAL, "level_layout: bad argument");
+    for (int l = 0; l < num_levels; ++l) {
+        const LevelGeom g = level_geom(H, W, l);
+        hl[l] = g.h; wl[l] = g.w; slab[l] = g.slab;
+    }
     return RAFTCORR_OK;
 }
 
+int raftcorr_level_positions(int H, int W, int level, int32_t* pos)
+{
+    if (H < 1 || W < 1 || level < 0 || level >= RAFTCORR_MAX_LEVELS || !pos)
+        return fail(RAFTCORR_EINVAL, "level_positions: bad argument");
+    const LevelGeom g = level_geom(H, W, level);
+    for (int y = 0; y < g.h; ++y)
+        for (int x = 0; x < g.w; ++x) pos[y * g.w + x] = level_pos(g, y, x);
+    return RAFTCORR_OK;
+}
+
+int64_t raftcorr_build_workspace_bytes(int B, int D, int H, int W)
+{
+    if (B < 1 || D < 1 || H < 1 || W < 1) return 0;
+    return (int64_t)build_workspace_bytes(B, D, H, W);
+}
+
+int64_t raftcorr_build_bwd_workspace_bytes(int B, int D, int H, int W)
+{
+    if (B < 1 || D < 1 || H < 1 || W < 1) return 0;
+    return (int64_t)build_bwd_workspace_bytes(B, D, H, W);
+}
+
 int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
-                           int num_levels, float* const* levels, void* stream)
+                           int num_levels, float* const* levels, void* workspace, int64_t workspace_bytes,
+                           void* stream)
 {
     int rc = check_dims("build_pyramid", B, H, W);
     if (rc) return rc;
@@ -84,7 +106,8 @@ int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D,
     LevelSet lv;
     rc = make_levels("build_pyramid", levels, H, W, num_levels, lv);
     if (rc) return rc;
-    return launch_build_pyramid(fmap1, fmap2, B, D, H, W, num_levels, lv, (hipStream_t)stream);
+    return launch_build_pyramid(fmap1, fmap2, B, D, H, W, num_levels, lv, workspace,
+                                workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
 int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels, int radius,
@@ -131,7 +154,8 @@ int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels, int B
 }
 
 int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
-                       int num_levels, float* const* dlevels, float* dfmap1, float* dfmap2, void* stream)
+                       int num_levels, float* const* dlevels, float* dfmap1, float* dfmap2,
+                       void* workspace, int64_t workspace_bytes, void* stream)
 {
     int rc = check_dims("build_bwd", B, H, W);
     if (rc) return rc;
@@ -140,7 +164,8 @@ int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int
     LevelSet dlv;
     rc = make_levels("build_bwd", dlevels, H, W, num_levels, dlv);
     if (rc) return rc;
-    return launch_build_bwd(fmap1, fmap2, B, D, H, W, num_levels, dlv, dfmap1, dfmap2, (hipStream_t)stream);
+    return launch_build_bwd(fmap1, fmap2, B, D, H, W, num_levels, dlv, dfmap1, dfmap2, workspace,
+                            workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
 static int alt_level_check(const char* who, int B, int N, int H1, int W1, int H2, int W2, int C, int r)
@@ -182,7 +207,7 @@ int raftcorr_alt_lookup_fwd(const float* fmap1, const float* const* fmap2_levels
     if (!fmap1 || !coords || !out) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: null pointer");
     if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: C=%d radius=%d", C, radius);
     LevelSet lv;
-    rc = make_levels("alt_lookup_fwd", fmap2_levels, H, W, num_levels, lv);
+    rc = make_levels("alt_lookup_fwd", fmap2_levels, H, W, num_levels, lv, false);
     if (rc) return rc;
     return launch_alt_lookup_fwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, out, (hipStream_t)stream);
 }
@@ -196,9 +221,9 @@ int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels
     if (!fmap1 || !coords || !dout || !dfmap1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: null pointer");
     if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: C=%d radius=%d", C, radius);
     LevelSet lv, dlv;
-    rc = make_levels("alt_lookup_bwd(fmap2)", fmap2_levels, H, W, num_levels, lv);
+    rc = make_levels("alt_lookup_bwd(fmap2)", fmap2_levels, H, W, num_levels, lv, false);
     if (rc) return rc;
-    rc = make_levels("alt_lookup_bwd(dfmap2)", dfmap2_levels, H, W, num_levels, dlv);
+    rc = make_levels("alt_lookup_bwd(dfmap2)", dfmap2_levels, H, W, num_levels, dlv, false);
     if (rc) return rc;
     return launch_alt_lookup_bwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, dout, dfmap1, dlv,
                                  (hipStream_t)stream);

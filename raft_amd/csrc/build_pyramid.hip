@@ -3,22 +3,26 @@
 // Replaces CorrBlock.__init__ / CorrBlock.corr of the reference (core/corr.py:13-27,53-61):
 //   torch.matmul(fmap1^T, fmap2) -> / sqrt(D) -> (L-1) x F.avg_pool2d(2, 2)
 // i.e. one sgemm, one elementwise pass and three pooling passes over a 200-260 MB volume.
-// Here it is one kernel: an fp32-MFMA contraction over D whose epilogue scales the tile and
-// produces the level-1..3 cells straight from the accumulator registers.
+// Here: a small pack pass (14 MB) + ONE kernel, an fp32-MFMA contraction over D whose epilogue
+// scales the tile and produces the level-1..3 cells straight from the accumulators.
 //
-// Tiling.  C[q, t] = sum_d F1[d, q] * F2[d, t].  Both feature maps are stored (D, N) with
-// the pixel index contiguous, which is exactly the operand shape of v_mfma_f32_32x32x2_f32
-// (lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]): LDS tiles are kept [k][m]
-// and every fragment read is one conflict-free ds_read_b32.
-//   block  = 256 threads = 4 waves, 128 queries x 128 targets
-//   wave w = 32 queries (rows 32w..32w+31) x all 128 targets  -> 4 accumulators of 32x32
-//   the 128 targets of a tile are an 8-row x 16-column PATCH of the target image, so every
-//   2x2, 4x4 and 8x8 pooling block lies inside one wave's registers:
-//     accumulator n  <-> patch rows 2n, 2n+1;  lane&15 <-> patch column, (lane>>4)&1 <-> row
-//     level 1 = lanes xor 1, xor 16;  level 2 = accumulators (2m, 2m+1) + lanes xor 2;
-//     level 3 = both halves + lanes xor 4.
-// K loop: BK = 32, register-staged double buffering (global loads of tile k+1 are in flight
-// while tile k is multiplied), one barrier per K tile.
+// C[q, p] = sum_d F1[d, q] * F2[d, t(p)]; the column order p is the patch-tile order of
+// layout.h.  Both operands are (D, pixels) with the pixel index contiguous, which is the
+// operand shape of v_mfma_f32_32x32x2_f32 (lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]), so no transposes anywhere.
+//
+//   pack    F1 -> [M tile][k][128] (zero padded), F2 -> [patch][k][(j, n)] (zero padded):
+//           tile panels are contiguous, the K loop has no bounds checks and each wave moves
+//           its share with 16-byte direct-to-LDS loads (global_load_lds_dwordx4).
+//   block   256 threads = 4 waves, 128 queries x one 8x16 patch (128 targets)
+//   wave w  32 queries x 128 targets: accumulator n <-> 4x8 tile n of the patch,
+//           MFMA column (lane & 31) <-> cell j of the tile
+//   K loop  BK = 32, two LDS buffers, the DMA of tile k+1 in flight while tile k is multiplied,
+//           one barrier per K tile; B fragments of the four accumulators are one ds_read_b128.
+//   epilog  level 0: every store instruction writes two full 128-B lines (one per lane half);
+//           level 1/2: DPP reductions inside the 16-lane rows (quad_perm, row_half_mirror,
+//           row_ror:8); level 3: one cross-row swizzle.  Sums are scaled by exact powers of
+//           two, so the values equal avg_pool2d's up to the order of the three additions.
 #include "common.h"
 
 namespace raftcorr {
@@ -26,34 +30,95 @@ namespace raftcorr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;      // queries per block
-constexpr int BN = 128;      // targets per block (8 x 16 patch)
 constexpr int BK = 32;
-constexpr int PATCH_H = 8;
-constexpr int PATCH_W = 16;
 constexpr int GROUP_M = 8;   // query tiles walked together (L2 reuse of the operand panels)
 
+// ---------------------------------------------------------------------------------------
+// pack: feature maps -> tile-major, zero-padded operand panels
+// ---------------------------------------------------------------------------------------
+// mode 0: dst[b][tile][k][c]           = src[b][k][tile*128 + c]                 (queries)
+// mode 1: dst[b][patch][k][j*4 + n]    = src[b][k][target(patch, n, j)]          (MFMA B operand)
+// mode 2: dst[b][patch][k][n*32 + j]   = src[b][k][target(patch, n, j)]          (volume column order)
+__global__ __launch_bounds__(256)
+void corr_pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                      int B, int D, int Dpad, int H, int W, int tiles, int mode)
+{
+    const int N = H * W;
+    const int PW = patches_w(W);
+    const size_t total = (size_t)B * tiles * Dpad * 128;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e & 127);
+        size_t r = e >> 7;
+        const int k = (int)(r % Dpad); r /= Dpad;
+        const int tile = (int)(r % tiles);
+        const int b = (int)(r / tiles);
+        int t = -1;
+        if (mode == 0) {
+            const int q = tile * 128 + c;
+            if (q < N) t = q;
+        } else {
+            const int n = (mode == 1) ? (c & 3) : (c >> 5);
+            const int j = (mode == 1) ? (c >> 2) : (c & 31);
+            const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
+            const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
+            const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
+            const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
+            if (y < H && x < W) t = y * W + x;
+        }
+        dst[e] = (t >= 0 && k < D) ? src[((size_t)b * D + k) * N + t] : 0.f;
+    }
+}
+
+int launch_pack(const float* src, float* dst, int B, int D, int Dpad, int H, int W, int tiles, int mode,
+                hipStream_t s)
+{
+    const size_t total = (size_t)B * tiles * Dpad * 128;
+    const unsigned g = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(corr_pack_kernel, dim3(g), dim3(256), 0, s, src, dst, B, D, Dpad, H, W, tiles, mode);
+    return check_launch("corr_pack_kernel");
+}
+
+// ---------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------
 struct BuildArgs {
-    const float* f1;
-    const float* f2;
-    LevelSet lv;
-    int B, D, H, W, N, L;
-    int tilesM, PH, PW, tilesN;
-    int nblk_per_b;
-    float inv_sqrt_d;   // used when exact (sqrt(D) is a power of two)
-    float sqrt_d;       // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
+    const float* f1p;     // [B][tilesM][Dpad][128]
+    const float* f2p;     // [B][tilesN][Dpad][128], (j, n) interleaved
+    float* lvl[4];
+    long long slab[4];    // elements per query slab, levels 0..3
+    int B, Dpad, N, L;
+    int tilesM, tilesN, nblk_per_b;
+    float inv_sqrt_d;     // used when sqrt(D) is a power of two (exact)
+    float sqrt_d;         // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
 };
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // i -> 7 - i inside groups of 8
+constexpr int DPP_ROR8 = 0x128;         // i -> (i + 8) & 15 inside a row == xor 8
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_chunk)
+{
+    // 64 lanes x 16 B: per-lane global source, LDS destination = chunk base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
+}
 
 template <bool EXACT_MUL>
 __global__ __launch_bounds__(256, 2)
 void corr_build_f32_kernel(BuildArgs p)
 {
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];   // [buf][A|B][k][128]
 
-    // ---- block -> (batch, query tile, target patch), XCD-aware ----------------------------
+    // ---- block -> (batch, query tile, patch), XCD-aware ----------------------------------
     // Blocks are dealt round-robin over the 8 XCDs; give every XCD a contiguous chunk of the
-    // tile list (bijective form, any grid size) and walk that chunk GROUP_M query tiles at a
-    // time, so the blocks resident together on one XCD share a few A and B panels in its L2.
+    // tile list (bijective form, any grid size) and walk it GROUP_M query tiles at a time, so
+    // the blocks resident together on one XCD share a few A and B panels in its L2.
     const int nwg = gridDim.x;
     const int orig = blockIdx.x;
     const int xcd = orig & 7;
@@ -68,41 +133,27 @@ void corr_build_f32_kernel(BuildArgs p)
     const int within = t - grp * per_group;
     const int tm = first_m + within % gsz;
     const int tn = within / gsz;
-    const int ph = tn / p.PW;
-    const int pw = tn - ph * p.PW;
     const int m0 = tm * BM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int N = p.N, D = p.D, H = p.H, W = p.W;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Dpad = p.Dpad;
 
-    // ---- staging addresses (fixed over the K loop) ---------------------------------------
-    const int c = tid & 127;          // column of the A / B tile this thread stages
-    const int r0 = tid >> 7;          // first k row (0/1), step 2
-    const int qa = m0 + c;
-    const bool va = qa < N;
-    const float* pa = p.f1 + (size_t)b * D * N + (va ? qa : 0);
-    const int h2s = ph * PATCH_H + (c >> 4);
-    const int w2s = pw * PATCH_W + (c & 15);
-    const bool vb = (h2s < H) && (w2s < W);
-    const float* pb = p.f2 + (size_t)b * D * N + (vb ? h2s * W + w2s : 0);
+    const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * Dpad * 128;
+    const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * Dpad * 128;
 
-    float ra[BK / 2], rb[BK / 2];
-    auto gload = [&](int k0) {
+    // stage K tile kt into LDS buffer buf: 16 KB of A + 16 KB of B, 4 + 4 DMA pieces per wave
+    auto stage = [&](int kt, int buf) {
+        float* la = smem + buf * (2 * BK * 128);
+        float* lb = la + BK * 128;
+        const float* ga = pa + (size_t)kt * BK * 128;
+        const float* gb = pb + (size_t)kt * BK * 128;
 #pragma unroll
-        for (int i = 0; i < BK / 2; ++i) {
-            const int k = k0 + r0 + 2 * i;
-            const bool vk = k < D;
-            ra[i] = (va && vk) ? pa[(size_t)k * N] : 0.f;
-            rb[i] = (vb && vk) ? pb[(size_t)k * N] : 0.f;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < BK / 2; ++i) {
-            As[buf][r0 + 2 * i][c] = ra[i];
-            Bs[buf][r0 + 2 * i][c] = rb[i];
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;              // 1 KiB pieces, 16 per operand tile
+            glds16(ga + piece * 256 + lane * 4, la + piece * 256);
+            glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
         }
     };
 
@@ -112,116 +163,156 @@ void corr_build_f32_kernel(BuildArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-    const int nk = (D + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
+    const int nk = Dpad / BK;
     const int kh = lane >> 5;       // which of the 2 k rows of an MFMA step this lane feeds
     const int l31 = lane & 31;
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        __syncthreads();            // tile kt has landed (vmcnt(0) precedes the barrier) and
+                                    // nobody still reads the buffer that is restaged next
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const float* la = smem + buf * (2 * BK * 128) + kh * 128 + wave * 32 + l31;
+        const float* lb = smem + buf * (2 * BK * 128) + BK * 128 + kh * 128 + l31 * 4;
+        float a_cur = la[0];
+        float4 b_cur = *(const float4*)lb;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a = As[buf][2 * kk + kh][wave * 32 + l31];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const float bv = Bs[buf][2 * kk + kh][n * 32 + l31];
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[n], 0, 0, 0);
+            float a_nxt = 0.f;
+            float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk + 1 < BK / 2) {
+                a_nxt = la[(kk + 1) * 256];
+                b_nxt = *(const float4*)(lb + (kk + 1) * 256);
             }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.w, acc[3], 0, 0, 0);
+            a_cur = a_nxt;
+            b_cur = b_nxt;
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: scale, store level 0, pool levels 1..3 in registers --------------------
+    // ---- epilogue ------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    const int dx = lane & 15;
-    const int dyl = (lane >> 4) & 1;
-    const int w2 = pw * PATCH_W + dx;
+    // Stores go through buffer descriptors that cover exactly this wave's valid query rows:
+    // rows past N (last query tile) and lanes that do not own a pooled cell get an offset
+    // outside the descriptor and are dropped by the hardware range check -- no branches.
+    const int q0w = m0 + wave * 32;
+    const int rows = min(32, p.N - q0w);
+    if (rows <= 0) return;                                   // wave-uniform
     const int L = p.L;
-    const int H1 = p.lv.h[1], W1 = p.lv.w[1];
-    const int H2 = p.lv.h[2], W2 = p.lv.w[2];
-    const int H3 = p.lv.h[3], W3 = p.lv.w[3];
-    float* __restrict__ o0 = p.lv.ptr[0];
-    float* __restrict__ o1 = p.lv.ptr[1];
-    float* __restrict__ o2 = p.lv.ptr[2];
-    float* __restrict__ o3 = p.lv.ptr[3];
+    const unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t r0, r1, r2, r3;
+    {
+        const size_t qb = (size_t)b * p.N + q0w;
+        r0 = __builtin_amdgcn_make_buffer_rsrc(p.lvl[0] + qb * p.slab[0], 0, (int)(rows * p.slab[0] * 4), 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc(L > 1 ? p.lvl[1] + qb * p.slab[1] : p.lvl[0], 0,
+                                               L > 1 ? (int)(rows * p.slab[1] * 4) : 0, 0x00020000);
+        r2 = __builtin_amdgcn_make_buffer_rsrc(L > 2 ? p.lvl[2] + qb * p.slab[2] : p.lvl[0], 0,
+                                               L > 2 ? (int)(rows * p.slab[2] * 4) : 0, 0x00020000);
+        r3 = __builtin_amdgcn_make_buffer_rsrc(L > 3 ? p.lvl[3] + qb * p.slab[3] : p.lvl[0], 0,
+                                               L > 3 ? (int)(rows * p.slab[3] * 4) : 0, 0x00020000);
+    }
+    const unsigned s0b = (unsigned)(p.slab[0] * 4), s1b = (unsigned)(p.slab[1] * 4);
+    const unsigned s2b = (unsigned)(p.slab[2] * 4), s3b = (unsigned)(p.slab[3] * 4);
+    const unsigned c0 = (unsigned)(tn * 128 + l31) * 4;                       // + n*128 bytes
+    const unsigned c1 = (unsigned)(tn * 32 + (lane & 3) * 8 + ((lane >> 2) & 7)) * 4;
+    const unsigned c2 = ((lane & 15) < 4) ? (unsigned)(tn * 8 + (lane & 15) * 2 + ((lane >> 4) & 1)) * 4 : OOB;
+    const unsigned c3 = ((lane & 31) < 2) ? (unsigned)(tn * 2 + (lane & 31)) * 4 : OOB;
+    const int quad = lane & 3, l15 = lane & 15;
 
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-        const int q = m0 + wave * 32 + row;
-        const bool vq = q < N;
-        const size_t qb = (size_t)b * N + q;
+        const unsigned row = (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * kh);
         float v[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             v[n] = EXACT_MUL ? acc[n][reg] * p.inv_sqrt_d : acc[n][reg] / p.sqrt_d;
-            const int h2 = ph * PATCH_H + 2 * n + dyl;
-            if (vq && h2 < H && w2 < W) o0[(qb * H + h2) * W + w2] = v[n];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[n]), r0, row * s0b + c0 + n * 128, 0, 0);
         }
         if (L > 1) {
-            float s1[4];
+            float t1[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float tt = v[n] + __shfl_xor(v[n], 1);
-                tt += __shfl_xor(tt, 16);
-                s1[n] = tt * 0.25f;
-                const int hc = ph * 4 + n, wc = pw * 8 + (dx >> 1);
-                if (vq && (lane & 17) == 0 && hc < H1 && wc < W1) o1[(qb * H1 + hc) * W1 + wc] = s1[n];
+                float s = v[n] + dpp<DPP_XOR1>(v[n]);
+                t1[n] = s + dpp<DPP_XOR2>(s);                 // 2x2 sum, in all 4 lanes of the quad
             }
+            const float lo1 = (quad & 1) ? t1[1] : t1[0], hi1 = (quad & 1) ? t1[3] : t1[2];
+            const float mine1 = (quad & 2) ? hi1 : lo1;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine1 * 0.25f), r1, row * s1b + c1, 0, 0);
             if (L > 2) {
-                float s2[2];
+                float t2[4];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    float u = s1[2 * m] + s1[2 * m + 1];
-                    u += __shfl_xor(u, 2);
-                    s2[m] = u * 0.25f;
-                    const int hc = ph * 2 + m, wc = pw * 4 + (dx >> 2);
-                    if (vq && (lane & 19) == 0 && hc < H2 && wc < W2) o2[(qb * H2 + hc) * W2 + wc] = s2[m];
+                for (int n = 0; n < 4; ++n) {
+                    float s = t1[n] + dpp<DPP_HALF_MIRROR>(t1[n]);
+                    t2[n] = s + dpp<DPP_ROR8>(s);             // 4x4 sum, in all 16 lanes of the row
                 }
+                const float lo2 = (l15 & 1) ? t2[1] : t2[0], hi2 = (l15 & 1) ? t2[3] : t2[2];
+                const float mine2 = (l15 & 2) ? hi2 : lo2;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine2 * 0.0625f), r2, row * s2b + c2, 0, 0);
                 if (L > 3) {
-                    float u = s2[0] + s2[1];
-                    u += __shfl_xor(u, 4);
-                    const float s3 = u * 0.25f;
-                    const int hc = ph, wc = pw * 2 + (dx >> 3);
-                    if (vq && (lane & 23) == 0 && hc < H3 && wc < W3) o3[(qb * H3 + hc) * W3 + wc] = s3;
+                    const float u0 = t2[0] + t2[2], u1 = t2[1] + t2[3];      // upper + lower tile
+                    const float mine = (lane & 1) ? u1 : u0;
+                    const float other = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mine), 0x401F));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((mine + other) * 0.015625f), r3, row * s3b + c3, 0, 0);
                 }
             }
         }
     }
 }
 
-// levels >= 4: plain 2x2 mean of the previous level (rare: RAFT uses 4 levels)
-__global__ void pool2x2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                               size_t M, int Hi, int Wi, int Ho, int Wo)
+// levels >= 4: 2x2 mean of the previous level (rare: RAFT uses 4 levels); output row-major
+__global__ void pool2x2_kernel(const float* __restrict__ in, float* __restrict__ out, size_t M,
+                               LevelGeom gi, LevelGeom go)
 {
-    const size_t total = M * (size_t)Ho * Wo;
+    const size_t total = M * (size_t)go.h * go.w;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
-        const int wo = (int)(e % Wo);
-        const size_t r = e / Wo;
-        const int ho = (int)(r % Ho);
-        const size_t m = r / Ho;
-        const float* s = in + (m * Hi + 2 * ho) * Wi + 2 * wo;
-        out[e] = ((s[0] + s[1]) + (s[Wi] + s[Wi + 1])) * 0.25f;
+        const int wo = (int)(e % go.w);
+        const size_t r = e / go.w;
+        const int ho = (int)(r % go.h);
+        const size_t m = r / go.h;
+        const float* s = in + m * gi.slab;
+        const float a = s[level_pos(gi, 2 * ho, 2 * wo)], b = s[level_pos(gi, 2 * ho, 2 * wo + 1)];
+        const float c = s[level_pos(gi, 2 * ho + 1, 2 * wo)], d = s[level_pos(gi, 2 * ho + 1, 2 * wo + 1)];
+        out[m * go.slab + level_pos(go, ho, wo)] = ((a + b) + (c + d)) * 0.25f;
     }
+}
+
+size_t build_workspace_bytes(int B, int D, int H, int W)
+{
+    const int N = H * W;
+    const size_t Dpad = (size_t)(D + BK - 1) / BK * BK;
+    const size_t tilesM = (N + BM - 1) / BM, tilesN = (size_t)patches_h(H) * patches_w(W);
+    return (size_t)B * Dpad * 128 * (tilesM + tilesN) * sizeof(float);
 }
 
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, hipStream_t s)
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
+    if (workspace_bytes < build_workspace_bytes(B, D, H, W) || !workspace)
+        return fail(RAFTCORR_EINVAL, "build_pyramid: workspace too small (%zu < %zu bytes)",
+                    workspace_bytes, build_workspace_bytes(B, D, H, W));
     BuildArgs a;
-    a.f1 = f1; a.f2 = f2; a.lv = lv;
-    for (int l = L; l < RAFTCORR_MAX_LEVELS; ++l) { a.lv.ptr[l] = nullptr; a.lv.h[l] = 0; a.lv.w[l] = 0; }
-    a.B = B; a.D = D; a.H = H; a.W = W; a.N = H * W; a.L = L < 4 ? L : 4;
+    a.B = B; a.N = H * W; a.L = L < 4 ? L : 4;
+    a.Dpad = (D + BK - 1) / BK * BK;
     a.tilesM = (a.N + BM - 1) / BM;
-    a.PH = (H + PATCH_H - 1) / PATCH_H;
-    a.PW = (W + PATCH_W - 1) / PATCH_W;
-    a.tilesN = a.PH * a.PW;
+    a.tilesN = patches_h(H) * patches_w(W);
     a.nblk_per_b = a.tilesM * a.tilesN;
+    float* f1p = (float*)workspace;
+    float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * 128;
+    int rc = launch_pack(f1, f1p, B, D, a.Dpad, H, W, a.tilesM, 0, s);
+    if (rc) return rc;
+    rc = launch_pack(f2, f2p, B, D, a.Dpad, H, W, a.tilesN, 1, s);
+    if (rc) return rc;
+    a.f1p = f1p; a.f2p = f2p;
+    for (int l = 0; l < 4; ++l) {
+        a.lvl[l] = l < L ? lv.ptr[l] : nullptr;
+        a.slab[l] = l < L ? (long long)lv.g[l].slab : 0;
+        if ((long long)32 * a.slab[l] * 4 > 0x7fffffffLL)
+            return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: level %d slab too large", l);
+    }
     const float sq = sqrtf((float)D);
     a.sqrt_d = sq;
     a.inv_sqrt_d = 1.0f / sq;
@@ -232,15 +323,15 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     dim3 grid((unsigned)nblk), block(256);
     if (exact) hipLaunchKernelGGL(corr_build_f32_kernel<true>, grid, block, 0, s, a);
     else       hipLaunchKernelGGL(corr_build_f32_kernel<false>, grid, block, 0, s, a);
-    int rc = check_launch("corr_build_f32_kernel");
+    rc = check_launch("corr_build_f32_kernel");
     if (rc) return rc;
     for (int l = 4; l < L; ++l) {
         const size_t M = (size_t)B * a.N;
-        const size_t total = M * lv.h[l] * lv.w[l];
+        const size_t total = M * lv.g[l].h * lv.g[l].w;
         if (total == 0) continue;
         const unsigned g = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(pool2x2_kernel, dim3(g), dim3(256), 0, s, lv.ptr[l - 1], lv.ptr[l], M,
-                           lv.h[l - 1], lv.w[l - 1], lv.h[l], lv.w[l]);
+                           lv.g[l - 1], lv.g[l]);
         rc = check_launch("pool2x2_kernel");
         if (rc) return rc;
     }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/raftcorr.h"
+#include "layout.h"
 
 namespace raftcorr {
 
@@ -10,22 +11,26 @@ namespace raftcorr {
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
-struct LevelSet {                 // by-value kernel argument: per-level pointers and sizes
+struct LevelSet {                 // by-value kernel argument: per-level pointers and geometry
     float* ptr[RAFTCORR_MAX_LEVELS];
-    int h[RAFTCORR_MAX_LEVELS];
-    int w[RAFTCORR_MAX_LEVELS];
+    LevelGeom g[RAFTCORR_MAX_LEVELS];
 };
 
 // launchers (each validates nothing: the extern "C" layer in api.hip does)
+size_t build_workspace_bytes(int B, int D, int H, int W);
+size_t build_bwd_workspace_bytes(int B, int D, int H, int W);
+int launch_pack(const float* src, float* dst, int B, int D, int Dpad, int H, int W, int tiles, int mode,
+                hipStream_t s);
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, hipStream_t s);
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
                       int mode, float* out, hipStream_t s);
 int launch_lookup_bwd(const LevelSet& lv, const LevelSet& dlv, bool have_dlevels, int B, int H, int W,
                       int L, int r, const float* coords, int mode, const float* dout,
                       float* dcoords, hipStream_t s);
 int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                     const LevelSet& dlv, float* df1, float* df2, hipStream_t s);
+                     const LevelSet& dlv, float* df1, float* df2, void* workspace, size_t workspace_bytes,
+                     hipStream_t s);
 int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, float* corr,
                          int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
 int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,

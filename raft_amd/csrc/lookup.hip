@@ -66,7 +66,8 @@ void corr_lookup_fwd_kernel(LookupArgs p)
     const int l = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
-    const int Hl = p.lv.h[l], Wl = p.lv.w[l];
+    const LevelGeom g = p.lv.g[l];
+    const int Hl = g.h, Wl = g.w;
     const float* __restrict__ vol = p.lv.ptr[l];
     const int N = p.N;
 
@@ -90,7 +91,7 @@ void corr_lookup_fwd_kernel(LookupArgs p)
         const int xi = sx0[qi] + tx, yi = sy0[qi] + ty;
         float v = 0.f;
         if (q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)
-            v = vol[(((size_t)b * N + q) * Hl + yi) * Wl + xi];
+            v = vol[((size_t)b * N + q) * g.slab + level_pos(g, yi, xi)];
         taps[qi * ST + t] = v;
     }
     __syncthreads();
@@ -146,7 +147,8 @@ void corr_lookup_bwd_kernel(LookupArgs p)
     const int l = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
-    const int Hl = p.dlv.h[l], Wl = p.dlv.w[l];
+    const LevelGeom geo = p.dlv.g[l];
+    const int Hl = geo.h, Wl = geo.w;
     float* __restrict__ dvol = p.dlv.ptr[l];
     const int N = p.N;
     const int C = p.L * rd2;
@@ -191,7 +193,7 @@ void corr_lookup_bwd_kernel(LookupArgs p)
         if (tx > 0 && ty < rd)  acc += gq[(tx - 1) * rd + ty] * (fx * (1.f - fy));
         if (tx < rd && ty > 0)  acc += gq[tx * rd + ty - 1] * ((1.f - fx) * fy);
         if (tx > 0 && ty > 0)   acc += gq[(tx - 1) * rd + ty - 1] * (fx * fy);
-        float* dst = dvol + (((size_t)b * N + q) * Hl + yi) * Wl + xi;
+        float* dst = dvol + ((size_t)b * N + q) * geo.slab + level_pos(geo, yi, xi);
         *dst += acc;
     }
 }
@@ -209,8 +211,9 @@ void corr_lookup_dcoords_kernel(LookupArgs p)
     float gx = 0.f, gy = 0.f;
     if (q < N) {
         for (int l = 0; l < p.L; ++l) {
-            const int Hl = p.lv.h[l], Wl = p.lv.w[l];
-            const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q) * Hl * Wl;
+            const LevelGeom g = p.lv.g[l];
+            const int Hl = g.h, Wl = g.w;
+            const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q) * g.slab;
             float x, y;
             load_xy(p, b, q, l, x, y);
             int x0, y0; float fx, fy;
@@ -221,7 +224,7 @@ void corr_lookup_dcoords_kernel(LookupArgs p)
                 const int a = ch / rd, bb = ch - a * rd;
                 const int xi = x0 - r + a, yi = y0 - r + bb;
                 auto tap = [&](int yy, int xx) -> float {
-                    return (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl) ? vol[(size_t)yy * Wl + xx] : 0.f;
+                    return (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl) ? vol[level_pos(g, yy, xx)] : 0.f;
                 };
                 const float t00 = tap(yi, xi), t01 = tap(yi, xi + 1);
                 const float t10 = tap(yi + 1, xi), t11 = tap(yi + 1, xi + 1);

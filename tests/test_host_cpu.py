@@ -22,29 +22,44 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().raftcorr_version() == 1
 
 
-def test_level_dims_match_avg_pool_floor():
+def test_level_layout_matches_avg_pool_floor_and_is_a_bijection():
+    import numpy as np
     from raft_amd import _lib
-    lib = _lib.load()
-    for (H, W, L) in [(55, 128, 4), (47, 156, 4), (50, 90, 4), (136, 240, 4), (13, 17, 2), (9, 9, 3)]:
-        hl = (ctypes.c_int32 * L)()
-        wl = (ctypes.c_int32 * L)()
-        assert lib.raftcorr_level_dims(H, W, L, hl, wl) == 0
+    for (H, W, L) in [(55, 128, 4), (47, 156, 4), (50, 90, 4), (136, 240, 4), (13, 17, 2), (9, 9, 3),
+                      (40, 72, 6)]:
+        lay = _lib.level_layout(H, W, L)
         x = torch.zeros(1, 1, H, W)
         exp = []
         for _ in range(L):
             exp.append(tuple(x.shape[-2:]))
-            x = torch.nn.functional.avg_pool2d(x, 2, stride=2)
-        assert [(hl[i], wl[i]) for i in range(L)] == exp == _lib.level_dims(H, W, L)
+            if min(x.shape[-2:]) >= 2:
+                x = torch.nn.functional.avg_pool2d(x, 2, stride=2)
+            else:
+                x = x[..., : x.shape[-2] // 2, : x.shape[-1] // 2]
+        assert [(h, w) for h, w, _ in lay] == exp == _lib.level_dims(H, W, L)
+        for l, (h, w, slab) in enumerate(lay):
+            pos = _lib.level_positions(H, W, l)
+            assert pos.shape == (h * w,)
+            assert len(np.unique(pos)) == h * w and (h * w == 0 or (pos.min() >= 0 and pos.max() < slab))
+        if L >= 4:      # pooled cells sit where the build kernel's epilogue and the fold put them
+            p = [_lib.level_positions(H, W, l).reshape(H >> l, W >> l) for l in range(4)]
+            for y in range(0, (H >> 3) << 3, 3):
+                for xx in range(0, (W >> 3) << 3, 5):
+                    c = int(p[0][y, xx]); patch, n, j = c >> 7, (c >> 5) & 3, c & 31
+                    assert patch * 32 + n * 8 + (j >> 2) == p[1][y // 2, xx // 2]
+                    assert patch * 8 + n * 2 + (j >> 4) == p[2][y // 4, xx // 4]
+                    assert patch * 2 + (n & 1) == p[3][y // 8, xx // 8]
 
 
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     from raft_amd import _lib
     lib = _lib.load()
     ptrs = (ctypes.c_void_p * 4)()
-    assert lib.raftcorr_build_pyramid(None, None, 1, 256, 55, 128, 4, ptrs, None) == -1
+    assert lib.raftcorr_build_pyramid(None, None, 1, 256, 55, 128, 4, ptrs, None, 0, None) == -1
     assert b"null" in lib.raftcorr_last_error()
-    assert lib.raftcorr_build_pyramid(8, 8, 0, 256, 55, 128, 4, ptrs, None) == -1
-    assert lib.raftcorr_build_pyramid(8, 8, 1, 256, 55, 128, 9, ptrs, None) == -1
+    assert lib.raftcorr_build_pyramid(8, 8, 0, 256, 55, 128, 4, ptrs, None, 0, None) == -1
+    assert lib.raftcorr_build_pyramid(8, 8, 1, 256, 55, 128, 9, ptrs, None, 0, None) == -1
+    assert lib.raftcorr_build_workspace_bytes(1, 256, 55, 128) == 4 * 256 * 128 * (55 + 56)
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, -1, 8, 0, 8, None) == -1
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, 4, 8, 7, 8, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 0, 4, None) == -1
