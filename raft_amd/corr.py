@@ -36,7 +36,15 @@ import contextlib
 _NULL = contextlib.nullcontext()
 
 
+try:                                    # raw hipStream_t of the current stream, without wrapper objects
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover
+    _raw_stream = None
+
+
 def _stream(t):
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -76,6 +84,10 @@ class _Pyramid:
         self.dflat = None         # gradient accumulator (allocated on first lookup backward)
         self.dptrs = None
         self._index = {}
+
+    def out_shape(self, radius, mode):
+        C = self.L * (2 * radius + 1) ** 2
+        return (self.B, self.N, C) if mode == _lib.MODE_FORK else (self.B, C, self.H, self.W)
 
     def slabs(self, flat):
         """Per level: (B*N, slab_l) view of the packed buffer (device layout)."""
@@ -160,16 +172,13 @@ class _BuildPyramid(torch.autograd.Function):
 
 def _lookup(pyr, coords, radius, mode):
     lib = _lib.load()
-    rd2 = (2 * radius + 1) ** 2
-    C = pyr.L * rd2
-    if mode == _lib.MODE_FORK:
-        out = torch.empty(pyr.B, pyr.N, C, dtype=torch.float32, device=coords.device)
-    else:
-        out = torch.empty(pyr.B, C, pyr.H, pyr.W, dtype=torch.float32, device=coords.device)
+    shape = pyr.out_shape(radius, mode)
+    out = torch.empty(shape, dtype=torch.float32, device=coords.device)
     with _guard(coords):
-        _lib.check(lib.raftcorr_lookup_fwd(pyr.ptrs, pyr.B, pyr.H, pyr.W, pyr.L, radius,
-                                           coords.data_ptr(), mode, out.data_ptr(), _stream(coords)),
-                   "lookup_fwd")
+        rc = lib.raftcorr_lookup_fwd(pyr.ptrs, pyr.B, pyr.H, pyr.W, pyr.L, radius,
+                                     coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
+    if rc:
+        _lib.check(rc, "lookup_fwd")
     return out
 
 
@@ -238,21 +247,23 @@ class CorrBlock:
         return self._logical
 
     def __call__(self, coords):
-        _require_cuda(coords=coords)
         p = self._pyr
-        if coords.dim() == 3:                                   # fork semantics, core/corr.py:29-51
+        if not coords.is_cuda:
+            raise RuntimeError("coords must be a CUDA tensor")
+        nd = coords.dim()
+        if nd == 3:                                             # fork semantics, core/corr.py:29-51
             mode = _lib.MODE_FORK
-            if coords.shape != (p.B, p.N, 2):
+            if tuple(coords.shape) != (p.B, p.N, 2):
                 raise RuntimeError(f"CorrBlock: coords must be ({p.B}, {p.N}, 2); got {tuple(coords.shape)}")
-        elif coords.dim() == 4:                                 # canonical RAFT, core/raft.py:125
+        elif nd == 4:                                           # canonical RAFT, core/raft.py:125
             mode = _lib.MODE_CANONICAL
-            if coords.shape != (p.B, 2, p.H, p.W):
+            if tuple(coords.shape) != (p.B, 2, p.H, p.W):
                 raise RuntimeError(f"CorrBlock: coords must be ({p.B}, 2, {p.H}, {p.W}); got {tuple(coords.shape)}")
         else:
             raise RuntimeError("CorrBlock: coords must be (B, N, 2) or (B, 2, H, W)")
-        coords = _f32c(coords)
-        track = torch.is_grad_enabled() and (self._anchor is not None or coords.requires_grad)
-        if not track:
+        if coords.dtype is not torch.float32 or not coords.is_contiguous():
+            coords = _f32c(coords)
+        if not (torch.is_grad_enabled() and (self._anchor is not None or coords.requires_grad)):
             return _lookup(p, coords, self.radius, mode)
         anchor = self._anchor if self._anchor is not None else \
             torch.zeros(1, dtype=torch.float32, device=coords.device)

@@ -11,12 +11,17 @@
 // with a = x offset (slow output index), b = y offset (fast), T[ty][tx] the volume entry at
 // (y0 - r + ty, x0 - r + tx) or 0 outside the level (grid_sample's zero padding).
 //
-// A block handles QB = 32 consecutive queries of one level:
+// A block handles QB = 32 consecutive queries of one level (grid.y = level):
 //   phase 0  32 threads split the coordinates (floor / fraction)          -> LDS
-//   phase 1  all threads gather the 32 x (2r+2)^2 taps, row segments of
-//            2r+2 contiguous floats per query                             -> LDS
+//   phase 1  all threads gather the 32 x (2r+2)^2 taps.  The kernel is latency-bound (one
+//            block = three dependent memory round trips), so all of a thread's loads are
+//            issued back to back into registers, branch-free (out-of-range taps read a
+//            valid dummy address and are zeroed by a select), with the level's address
+//            arithmetic (patch-tile order, layout.h) resolved at compile time     -> LDS
 //   phase 2  all threads blend 4 LDS taps per output and store coalesced: along the
 //            channel dim for the (B,N,C) layout, along the query dim for (B,C,H,W).
+//            Output stores are non-temporal: the result is consumed by another kernel and
+//            should not evict volume lines that the next iteration's windows re-touch.
 // The backward pass mirrors it: dOut tile -> LDS, each tap's gradient is the 2x2 box
 // filter of dOut, added to d(level) with a plain read-modify-write: a (query, tap) cell
 // belongs to exactly one thread of one block, so no atomics are needed.
@@ -49,50 +54,119 @@ __device__ __forceinline__ void load_xy(const LookupArgs& p, int b, int q, int l
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(256)
-void corr_lookup_fwd_kernel(LookupArgs p)
+// level_pos (layout.h) with the level kind known at compile time
+template <int KIND>
+__device__ __forceinline__ int pos_k(int pw, int w, int y, int x)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (KIND == 0) {
+        const int patch = (y >> 3) * pw + (x >> 4);
+        const int n = (((y >> 2) & 1) << 1) | ((x >> 3) & 1);
+        const int dy = y & 3, dx = x & 7;
+        const int j = (dx & 1) | ((dy & 1) << 1) | ((dy >> 1) << 2) | (((dx >> 1) & 1) << 3) | ((dx >> 2) << 4);
+        return patch * 128 + n * 32 + j;
+    } else if (KIND == 1) {
+        const int patch = (y >> 2) * pw + (x >> 3);
+        const int n = (((y >> 1) & 1) << 1) | ((x >> 2) & 1);
+        return patch * 32 + n * 8 + ((y & 1) | ((x & 1) << 1) | (((x >> 1) & 1) << 2));
+    } else if (KIND == 2) {
+        const int patch = (y >> 1) * pw + (x >> 2);
+        const int n = ((y & 1) << 1) | ((x >> 1) & 1);
+        return patch * 8 + n * 2 + (x & 1);
+    } else if (KIND == 3) {
+        return (y * pw + (x >> 1)) * 2 + (x & 1);
+    }
+    return y * w + x;
+}
+
+struct LookupSmem {
+    float* tile;   // fwd: [QB][ST] taps;  bwd: [QB][SG] dOut
+    float* sfx; float* sfy; int* sx0; int* sy0;
+};
+
+__device__ __forceinline__ LookupSmem carve(float* smem, int r, bool bwd)
+{
+    const int T = 2 * r + 2, rd = 2 * r + 1;
+    const int stride = bwd ? ((rd * rd) | 1) : ((T * T) | 1);
+    LookupSmem s;
+    s.tile = smem;
+    s.sfx = smem + QB * stride;
+    s.sfy = s.sfx + QB;
+    s.sx0 = (int*)(s.sfy + QB);
+    s.sy0 = s.sx0 + QB;
+    return s;
+}
+
+__device__ __forceinline__ void split_block_coords(const LookupArgs& p, const LookupSmem& s, int b, int q0,
+                                                   int l, int r)
+{
+    const int tid = threadIdx.x;
+    if (tid < QB) {
+        const int q = q0 + tid;
+        float x = 0.f, y = 0.f;
+        if (q < p.N) load_xy(p, b, q, l, x, y);
+        int x0, y0; float fx, fy;
+        split_coord(x, x0, fx);
+        split_coord(y, y0, fy);
+        s.sx0[tid] = x0 - r; s.sy0[tid] = y0 - r; s.sfx[tid] = fx; s.sfy[tid] = fy;
+    }
+}
+
+template <int R, int KIND>
+__device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem)
+{
     const int r = (R >= 0) ? R : p.r;
     const int T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
     const int ST = TT | 1;                       // odd stride: conflict-free query-major reads
-    float* taps = smem;                          // [QB][ST]
-    float* sfx = smem + QB * ST;                 // [QB]
-    float* sfy = sfx + QB;
-    int* sx0 = (int*)(sfy + QB);
-    int* sy0 = sx0 + QB;
+    const LookupSmem s = carve(smem, r, false);
+    float* taps = s.tile;
 
     const int l = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
     const LevelGeom g = p.lv.g[l];
     const int Hl = g.h, Wl = g.w;
-    const float* __restrict__ vol = p.lv.ptr[l];
     const int N = p.N;
+    const float* __restrict__ vol = p.lv.ptr[l] + (size_t)b * N * g.slab;
 
-    if (tid < QB) {
-        const int q = q0 + tid;
-        float x = 0.f, y = 0.f;
-        if (q < N) load_xy(p, b, q, l, x, y);
-        int x0, y0; float fx, fy;
-        split_coord(x, x0, fx);
-        split_coord(y, y0, fy);
-        sx0[tid] = x0 - r; sy0[tid] = y0 - r; sfx[tid] = fx; sfy[tid] = fy;
-    }
+    split_block_coords(p, s, b, q0, l, r);
     __syncthreads();
 
-    for (int e = tid; e < QB * TT; e += 256) {
-        const int qi = e / TT;
-        const int t = e - qi * TT;
-        const int ty = t / T;
-        const int tx = t - ty * T;
-        const int q = q0 + qi;
-        const int xi = sx0[qi] + tx, yi = sy0[qi] + ty;
-        float v = 0.f;
-        if (q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)
-            v = vol[((size_t)b * N + q) * g.slab + level_pos(g, yi, xi)];
-        taps[qi * ST + t] = v;
+    if (R >= 0) {
+        constexpr int Rc = R >= 0 ? R : 0;
+        constexpr int NIT = (QB * (2 * Rc + 2) * (2 * Rc + 2) + 255) / 256;
+        float v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qe = e / TT;
+            const int qi = min(qe, QB - 1);
+            const int t = e - qe * TT;
+            const int ty = t / T, tx = t - ty * T;
+            const int q = q0 + qi;
+            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
+            ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl;
+            const int pos = ok[i] ? pos_k<KIND>(g.pw, Wl, yi, xi) : 0;
+            v[i] = vol[(size_t)(ok[i] ? q : 0) * g.slab + pos];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qe = e / TT;
+            if (e < QB * TT) taps[qe * ST + (e - qe * TT)] = ok[i] ? v[i] : 0.f;
+        }
+    } else {
+        for (int e = tid; e < QB * TT; e += 256) {
+            const int qi = e / TT;
+            const int t = e - qi * TT;
+            const int ty = t / T, tx = t - ty * T;
+            const int q = q0 + qi;
+            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
+            float v = 0.f;
+            if (q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)
+                v = vol[(size_t)q * g.slab + pos_k<KIND>(g.pw, Wl, yi, xi)];
+            taps[qi * ST + t] = v;
+        }
     }
     __syncthreads();
 
@@ -106,18 +180,18 @@ void corr_lookup_fwd_kernel(LookupArgs p)
             const int a = ch / rd;
             const int bb = ch - a * rd;
             if (q0 + qi >= N) break;
-            const float fx = sfx[qi], fy = sfy[qi];
+            const float fx = s.sfx[qi], fy = s.sfy[qi];
             const float* tp = taps + qi * ST + bb * T + a;
             const float o = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
                             tp[T] * ((1.f - fx) * fy) + tp[T + 1] * (fx * fy);
-            out[(size_t)qi * C + ch] = o;
+            __builtin_nontemporal_store(o, &out[(size_t)qi * C + ch]);
         }
     } else {
         // out (B, C, N): lanes run along the query dim
         float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
         const int qi = tid & (QB - 1);
         const bool vq = q0 + qi < N;
-        const float fx = sfx[qi], fy = sfy[qi];
+        const float fx = s.sfx[qi], fy = s.sfy[qi];
         const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
         const float w10 = (1.f - fx) * fy, w11 = fx * fy;
         for (int ch = tid / QB; ch < rd2; ch += 256 / QB) {
@@ -125,43 +199,44 @@ void corr_lookup_fwd_kernel(LookupArgs p)
             const int bb = ch - a * rd;
             const float* tp = taps + qi * ST + bb * T + a;
             const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
-            if (vq) out[(size_t)ch * N + qi] = o;
+            if (vq) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]);
         }
     }
 }
 
 template <int R>
 __global__ __launch_bounds__(256)
-void corr_lookup_bwd_kernel(LookupArgs p)
+void corr_lookup_fwd_kernel(LookupArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    switch (p.lv.g[blockIdx.y].kind) {           // block-uniform
+    case 0: lookup_fwd_body<R, 0>(p, smem); break;
+    case 1: lookup_fwd_body<R, 1>(p, smem); break;
+    case 2: lookup_fwd_body<R, 2>(p, smem); break;
+    case 3: lookup_fwd_body<R, 3>(p, smem); break;
+    default: lookup_fwd_body<R, 4>(p, smem); break;
+    }
+}
+
+template <int R, int KIND>
+__device__ __forceinline__ void lookup_bwd_body(const LookupArgs& p, float* smem)
+{
     const int r = (R >= 0) ? R : p.r;
     const int T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
     const int SG = rd2 | 1;
-    float* g = smem;                             // [QB][SG]  dOut tile
-    float* sfx = smem + QB * SG;
-    float* sfy = sfx + QB;
-    int* sx0 = (int*)(sfy + QB);
-    int* sy0 = sx0 + QB;
+    const LookupSmem s = carve(smem, r, true);
+    float* g = s.tile;                           // [QB][SG]  dOut tile
 
     const int l = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
     const LevelGeom geo = p.dlv.g[l];
     const int Hl = geo.h, Wl = geo.w;
-    float* __restrict__ dvol = p.dlv.ptr[l];
     const int N = p.N;
+    float* __restrict__ dvol = p.dlv.ptr[l] + (size_t)b * N * geo.slab;
     const int C = p.L * rd2;
 
-    if (tid < QB) {
-        const int q = q0 + tid;
-        float x = 0.f, y = 0.f;
-        if (q < N) load_xy(p, b, q, l, x, y);
-        int x0, y0; float fx, fy;
-        split_coord(x, x0, fx);
-        split_coord(y, y0, fy);
-        sx0[tid] = x0 - r; sy0[tid] = y0 - r; sfx[tid] = fx; sfy[tid] = fy;
-    }
+    split_block_coords(p, s, b, q0, l, r);
     if (p.mode == RAFTCORR_MODE_FORK) {
         const float* __restrict__ d = p.dout + ((size_t)b * N + q0) * C + l * rd2;
         for (int e = tid; e < QB * rd2; e += 256) {
@@ -178,23 +253,71 @@ void corr_lookup_bwd_kernel(LookupArgs p)
     }
     __syncthreads();
 
-    for (int e = tid; e < QB * TT; e += 256) {
-        const int qi = e / TT;
-        const int t = e - qi * TT;
-        const int ty = t / T;
-        const int tx = t - ty * T;
-        const int q = q0 + qi;
-        const int xi = sx0[qi] + tx, yi = sy0[qi] + ty;
-        if (!(q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)) continue;
-        const float fx = sfx[qi], fy = sfy[qi];
+    auto tap_grad = [&](int qi, int tx, int ty) -> float {
+        const float fx = s.sfx[qi], fy = s.sfy[qi];
         const float* gq = g + qi * SG;           // channel = a*rd + b, a <-> x, b <-> y
         float acc = 0.f;
         if (tx < rd && ty < rd) acc += gq[tx * rd + ty] * ((1.f - fx) * (1.f - fy));
         if (tx > 0 && ty < rd)  acc += gq[(tx - 1) * rd + ty] * (fx * (1.f - fy));
         if (tx < rd && ty > 0)  acc += gq[tx * rd + ty - 1] * ((1.f - fx) * fy);
         if (tx > 0 && ty > 0)   acc += gq[(tx - 1) * rd + ty - 1] * (fx * fy);
-        float* dst = dvol + ((size_t)b * N + q) * geo.slab + level_pos(geo, yi, xi);
-        *dst += acc;
+        return acc;
+    };
+
+    if (R >= 0) {
+        constexpr int Rc = R >= 0 ? R : 0;
+        constexpr int NIT = (QB * (2 * Rc + 2) * (2 * Rc + 2) + 255) / 256;
+        float old[NIT];
+        size_t off[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {          // all read-modify-write loads in flight together
+            const int e = tid + i * 256;
+            const int qe = e / TT;
+            const int qi = min(qe, QB - 1);
+            const int t = e - qe * TT;
+            const int ty = t / T, tx = t - ty * T;
+            const int q = q0 + qi;
+            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
+            ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl;
+            const int pos = ok[i] ? pos_k<KIND>(geo.pw, Wl, yi, xi) : 0;
+            off[i] = (size_t)(ok[i] ? q : 0) * geo.slab + pos;
+            old[i] = dvol[off[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qe = e / TT;
+            const int qi = min(qe, QB - 1);
+            const int t = e - qe * TT;
+            const int ty = t / T, tx = t - ty * T;
+            if (ok[i]) dvol[off[i]] = old[i] + tap_grad(qi, tx, ty);
+        }
+    } else {
+        for (int e = tid; e < QB * TT; e += 256) {
+            const int qi = e / TT;
+            const int t = e - qi * TT;
+            const int ty = t / T, tx = t - ty * T;
+            const int q = q0 + qi;
+            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
+            if (!(q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)) continue;
+            float* d = dvol + (size_t)q * geo.slab + pos_k<KIND>(geo.pw, Wl, yi, xi);
+            *d += tap_grad(qi, tx, ty);
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256)
+void corr_lookup_bwd_kernel(LookupArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    switch (p.dlv.g[blockIdx.y].kind) {
+    case 0: lookup_bwd_body<R, 0>(p, smem); break;
+    case 1: lookup_bwd_body<R, 1>(p, smem); break;
+    case 2: lookup_bwd_body<R, 2>(p, smem); break;
+    case 3: lookup_bwd_body<R, 3>(p, smem); break;
+    default: lookup_bwd_body<R, 4>(p, smem); break;
     }
 }
 
@@ -202,12 +325,11 @@ void corr_lookup_bwd_kernel(LookupArgs p)
 __global__ __launch_bounds__(256)
 void corr_lookup_dcoords_kernel(LookupArgs p)
 {
-    const int r = p.r, T = 2 * r + 2, rd = 2 * r + 1, rd2 = rd * rd;
+    const int r = p.r, rd = 2 * r + 1, rd2 = rd * rd;
     const int b = blockIdx.z;
     const int q = blockIdx.x * QB + (threadIdx.x >> 3);
     const int sub = threadIdx.x & 7;
     const int N = p.N, C = p.L * rd2;
-    (void)T;
     float gx = 0.f, gy = 0.f;
     if (q < N) {
         for (int l = 0; l < p.L; ++l) {
@@ -234,8 +356,8 @@ void corr_lookup_dcoords_kernel(LookupArgs p)
                 sx += d * ((1.f - fy) * (t01 - t00) + fy * (t11 - t10));
                 sy += d * ((1.f - fx) * (t10 - t00) + fx * (t11 - t01));
             }
-            const float s = (p.mode == RAFTCORR_MODE_FORK) ? 1.f : 1.0f / (float)(1 << l);
-            gx += sx * s; gy += sy * s;
+            const float sc = (p.mode == RAFTCORR_MODE_FORK) ? 1.f : 1.0f / (float)(1 << l);
+            gx += sx * sc; gy += sy * sc;
         }
     }
     for (int m = 1; m < 8; m <<= 1) { gx += __shfl_xor(gx, m); gy += __shfl_xor(gy, m); }

@@ -1,0 +1,312 @@
+// Experiment harness (not part of the product): times variants of the lookup kernel structure
+// with hipEvents over back-to-back launches.  Build: see tools/Makefile.  Run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "../raft_amd/csrc/layout.h"
+using namespace raftcorr;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+constexpr int QB = 32, R = 4, T = 2 * R + 2, TT = T * T, RD = 2 * R + 1, RD2 = RD * RD, ST = TT | 1;
+
+struct Args {
+    const float* lvl[4]; LevelGeom g[4];
+    const float* coords; float* out; int N, L;
+};
+
+// flags: 1 = no coords load, 2 = no tap loads, 4 = no stores, 8 = nothing at all
+template <int FLAGS>
+__global__ __launch_bounds__(256) void k_base(Args p)
+{
+    __shared__ float taps[QB * ST];
+    __shared__ float sfx[QB], sfy[QB];
+    __shared__ int sx0[QB], sy0[QB];
+    if (FLAGS & 8) return;
+    const int l = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x, N = p.N;
+    const LevelGeom g = p.g[l];
+    const float* __restrict__ vol = p.lvl[l];
+    if (tid < QB) {
+        const int q = q0 + tid;
+        float x = (float)(q % 128), y = (float)(q / 128);
+        if (!(FLAGS & 1) && q < N) { x = p.coords[q]; y = p.coords[N + q]; }
+        const float s = 1.0f / (float)(1 << l); x *= s; y *= s;
+        float fx0 = floorf(x), fy0 = floorf(y);
+        sx0[tid] = (int)fx0 - R; sy0[tid] = (int)fy0 - R; sfx[tid] = x - fx0; sfy[tid] = y - fy0;
+    }
+    __syncthreads();
+    {
+        constexpr int NIT = (QB * TT + 255) / 256;
+        float v[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qi = e / TT, t = e - qi * TT, ty = t / T, tx = t - ty * T;
+            v[i] = 0.f;
+            if (e < QB * TT) {
+                const int q = q0 + qi, xi = sx0[qi] + tx, yi = sy0[qi] + ty;
+                if (!(FLAGS & 2) && q < N && xi >= 0 && xi < g.w && yi >= 0 && yi < g.h)
+                    v[i] = vol[(size_t)((FLAGS & 16) ? (q & 63) : q) * g.slab + level_pos(g, yi, xi)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            if (e < QB * TT) { const int qi = e / TT, t = e - qi * TT; taps[qi * ST + t] = v[i]; }
+        }
+    }
+    __syncthreads();
+    const int C = p.L * RD2;
+    float* __restrict__ out = p.out + (size_t)(l * RD2) * N + q0;
+    const int qi = tid & (QB - 1);
+    const bool vq = q0 + qi < N;
+    const float fx = sfx[qi], fy = sfy[qi];
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    float keep = 0.f;
+    for (int ch = tid / QB; ch < RD2; ch += 256 / QB) {
+        const int a = ch / RD, bb = ch - a * RD;
+        const float* tp = taps + qi * ST + bb * T + a;
+        const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
+        if (FLAGS & 4) keep += o; else if (vq) { if (FLAGS & 32) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]); else out[(size_t)ch * N + qi] = o; }
+    }
+    if ((FLAGS & 4) && keep == 123.456f) out[0] = keep;
+    (void)C;
+}
+
+
+// timing-only variant: per (query, level) fetch whole 128-B lines with 16-B loads
+// (levels 0/1: the 4x8 tiles under the window; levels 2/3: the whole slab), QB2 queries per block
+template <int QB2, int FLAGS>
+__global__ __launch_bounds__(256) void k_lines(Args p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* tiles = sm;                       // [QB2][12*32] or slab
+    __shared__ float sfx[32], sfy[32];
+    __shared__ int sx0[32], sy0[32];
+    const int l = blockIdx.y, q0 = blockIdx.x * QB2, tid = threadIdx.x, N = p.N;
+    const LevelGeom g = p.g[l];
+    const float* __restrict__ vol = p.lvl[l];
+    if (tid < QB2) {
+        const int q = q0 + tid;
+        float x = 0, y = 0;
+        if (q < N) { x = p.coords[q]; y = p.coords[N + q]; }
+        const float s = 1.0f / (float)(1 << l); x *= s; y *= s;
+        float fx0 = floorf(x), fy0 = floorf(y);
+        sx0[tid] = (int)fx0 - R; sy0[tid] = (int)fy0 - R; sfx[tid] = x - fx0; sfy[tid] = y - fy0;
+    }
+    __syncthreads();
+    const int PER = 12 * 8;
+    if (l < 2) {
+        const int th = (g.h + 3) >> 2, tw = (g.w + 7) >> 3;
+        for (int e = tid; e < QB2 * PER; e += 256) {
+            const int qi = e / PER, rem = e - qi * PER, tile = rem >> 3, part = rem & 7;
+            const int tr = tile / 3, tc = tile - tr * 3;
+            const int ys = sy0[qi], xs = sx0[qi];
+            const int tyy = (ys >> 2) + tr, txx = (xs >> 3) + tc;
+            const int q = q0 + qi;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (q < N && tyy <= ((ys + 9) >> 2) && txx <= ((xs + 9) >> 3) && tyy >= 0 && tyy < th && txx >= 0 && txx < tw) {
+                int pos;
+                if (l == 0) pos = ((tyy >> 1) * g.pw + (txx >> 1)) * 128 + (((tyy & 1) << 1) | (txx & 1)) * 32 + part * 4;
+                else pos = (tyy * g.pw + txx) * 32 + part * 4;
+                v = *(const float4*)(vol + (size_t)q * g.slab + pos);
+            }
+            *(float4*)(tiles + qi * 384 + tile * 32 + part * 4) = v;
+        }
+    } else {
+        const int chunks = (int)(g.slab >> 2);   // float4 per slab
+        for (int e = tid; e < QB2 * chunks; e += 256) {
+            const int qi = e / chunks, c = e - qi * chunks, q = q0 + qi;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (q < N) v = *(const float4*)(vol + (size_t)q * g.slab + c * 4);
+            *(float4*)(tiles + qi * 448 + c * 4) = v;
+        }
+    }
+    __syncthreads();
+    float* __restrict__ out = p.out + (size_t)(l * RD2) * N + q0;
+    const int qi = tid & (QB2 - 1);
+    const bool vq = q0 + qi < N;
+    const float fx = sfx[qi], fy = sfy[qi];
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    for (int ch = tid / QB2; ch < RD2; ch += 256 / QB2) {
+        const int a = ch / RD, bb = ch - a * RD;
+        const float* tp = tiles + qi * 384 + bb * T + a;       // garbage addressing: timing only
+        const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
+        if (vq) { if (FLAGS & 32) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]); else out[(size_t)ch * N + qi] = o; }
+    }
+}
+
+
+template <int KIND> __device__ __forceinline__ int pos_k(int pw, int w, int y, int x)
+{
+    if (KIND == 0) {
+        const int patch = (y >> 3) * pw + (x >> 4);
+        const int n = (((y >> 2) & 1) << 1) | ((x >> 3) & 1);
+        const int dy = y & 3, dx = x & 7;
+        const int j = (dx & 1) | ((dy & 1) << 1) | ((dy >> 1) << 2) | (((dx >> 1) & 1) << 3) | ((dx >> 2) << 4);
+        return patch * 128 + n * 32 + j;
+    } else if (KIND == 1) {
+        const int patch = (y >> 2) * pw + (x >> 3);
+        const int n = (((y >> 1) & 1) << 1) | ((x >> 2) & 1);
+        return patch * 32 + n * 8 + ((y & 1) | ((x & 1) << 1) | (((x >> 1) & 1) << 2));
+    } else if (KIND == 2) {
+        const int patch = (y >> 1) * pw + (x >> 2);
+        const int n = ((y & 1) << 1) | ((x >> 1) & 1);
+        return patch * 8 + n * 2 + (x & 1);
+    } else if (KIND == 3) {
+        return (y * pw + (x >> 1)) * 2 + (x & 1);
+    }
+    return y * w + x;
+}
+
+template <int KIND, int FLAGS>
+__device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, float* sfy, int* sx0, int* sy0)
+{
+    const int l = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x, N = p.N;
+    const LevelGeom g = p.g[l];
+    const float* __restrict__ vol = p.lvl[l];
+    if (tid < QB) {
+        const int q = q0 + tid;
+        float x = 0, y = 0;
+        if (q < N) { x = p.coords[q]; y = p.coords[N + q]; }
+        const float s = 1.0f / (float)(1 << l); x *= s; y *= s;
+        float fx0 = floorf(x), fy0 = floorf(y);
+        sx0[tid] = (int)fx0 - R; sy0[tid] = (int)fy0 - R; sfx[tid] = x - fx0; sfy[tid] = y - fy0;
+    }
+    __syncthreads();
+    {
+        constexpr int NIT = (QB * TT + 255) / 256;
+        float v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qi = min(e / TT, QB - 1), t = e - (e / TT) * TT, ty = t / T, tx = t - ty * T;
+            const int q = q0 + qi, xi = sx0[qi] + tx, yi = sy0[qi] + ty;
+            ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < g.w && yi >= 0 && yi < g.h;
+            const int pos = ok[i] ? pos_k<KIND>(g.pw, g.w, yi, xi) : 0;
+            v[i] = vol[(size_t)(ok[i] ? q : 0) * g.slab + pos];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            if (e < QB * TT) taps[(e / TT) * ST + (e - (e / TT) * TT)] = ok[i] ? v[i] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* __restrict__ out = p.out + (size_t)(l * RD2) * N + q0;
+    const int qi = tid & (QB - 1);
+    const bool vq = q0 + qi < N;
+    const float fx = sfx[qi], fy = sfy[qi];
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+#pragma unroll
+    for (int i = 0; i < (RD2 + 7) / 8; ++i) {
+        const int ch = tid / QB + i * 8;
+        if (ch < RD2) {
+            const int a = ch / RD, bb = ch - a * RD;
+            const float* tp = taps + qi * ST + bb * T + a;
+            const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
+            if (vq) { if (FLAGS & 32) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]); else out[(size_t)ch * N + qi] = o; }
+        }
+    }
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) void k_v2(Args p)
+{
+    __shared__ float taps[QB * ST];
+    __shared__ float sfx[QB], sfy[QB];
+    __shared__ int sx0[QB], sy0[QB];
+    switch (p.g[blockIdx.y].kind) {
+    case 0: body2<0, FLAGS>(p, taps, sfx, sfy, sx0, sy0); break;
+    case 1: body2<1, FLAGS>(p, taps, sfx, sfy, sx0, sy0); break;
+    case 2: body2<2, FLAGS>(p, taps, sfx, sfy, sx0, sy0); break;
+    case 3: body2<3, FLAGS>(p, taps, sfx, sfy, sx0, sy0); break;
+    default: body2<4, FLAGS>(p, taps, sfx, sfy, sx0, sy0); break;
+    }
+}
+
+template <typename F> float timeit(F launch, int iters = 200)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 20; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+}
+
+int main()
+{
+    const int H = 55, W = 128, N = H * W, L = 4, NC = 32;
+    Args a; a.N = N; a.L = L;
+    for (int l = 0; l < L; ++l) {
+        a.g[l] = level_geom(H, W, l);
+        size_t n = (size_t)N * a.g[l].slab;
+        float* d; CK(hipMalloc(&d, n * 4));
+        std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) >> 20) * 1e-3f;
+        CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice)); a.lvl[l] = d;
+    }
+    std::vector<float*> dco(NC);
+    std::vector<float> drift(2 * N, 0.f);
+    srand(1);
+    auto gauss = []() { float u = (rand() + 1.f) / ((float)RAND_MAX + 2.f), v = (rand() + 1.f) / ((float)RAND_MAX + 2.f); return sqrtf(-2 * logf(u)) * cosf(6.2831853f * v); };
+    for (int k = 0; k < NC; ++k) {
+        std::vector<float> c(2 * N);
+        for (int q = 0; q < N; ++q) { c[q] = q % W + drift[q]; c[N + q] = q / W + drift[N + q]; }
+        CK(hipMalloc(&dco[k], 2 * N * 4)); CK(hipMemcpy(dco[k], c.data(), 2 * N * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < 2 * N; ++i) drift[i] += 3.f * gauss();
+    }
+    float* out; CK(hipMalloc(&out, (size_t)L * RD2 * N * 4));
+    a.out = out;
+    dim3 grid((N + QB - 1) / QB, L), block(256);
+#define RUN(name, K) printf("%-34s %7.2f us\n", name, timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL(K, grid, block, 0, 0, a); }))
+    RUN("empty kernel (launch floor)", k_base<8>);
+    RUN("base", k_base<0>);
+    RUN("base, no coords load", k_base<1>);
+    RUN("base, no tap loads", k_base<2>);
+    RUN("base, no stores", k_base<4>);
+    RUN("base, no taps, no stores", k_base<6>);
+    RUN("base, no coords/taps/stores", k_base<7>);
+    RUN("taps from 64 L2-resident slabs", k_base<16>);
+    RUN("nontemporal stores", k_base<32>);
+    RUN("L2-resident taps + nt stores", k_base<48>);
+    {
+        for (int gb : {1, 64, 220, 880, 3520}) {
+            char nm[64]; snprintf(nm, 64, "empty kernel, %d blocks x 256", gb);
+            printf("%-34s %7.2f us\n", nm, timeit([&](int i) { hipLaunchKernelGGL(k_base<8>, dim3(gb), block, 0, 0, a); }));
+        }
+        RUN("v2 (kind-templated, branch-free)", k_v2<0>);
+        RUN("v2 nt", k_v2<32>);
+        {   // correctness of v2 vs base
+            std::vector<float> o1((size_t)L * RD2 * N), o2(o1.size());
+            a.coords = dco[7];
+            hipLaunchKernelGGL(k_base<0>, grid, block, 0, 0, a); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(o1.data(), out, o1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemset(out, 0, o1.size() * 4));
+            hipLaunchKernelGGL(k_v2<32>, grid, block, 0, 0, a); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(o2.data(), out, o2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t i = 0; i < o1.size(); ++i) md = fmax(md, fabs(o1[i] - o2[i]));
+            printf("v2 vs base max diff %g\n", md);
+            int shown = 0; size_t bad = 0;
+            for (size_t i = 0; i < o1.size(); ++i) if (fabs(o1[i] - o2[i]) > 1e-4) { bad++; if (shown++ < 8) printf("  idx %zu (ch %zu q %zu) base %g v2 %g\n", i, i / N, i % N, o1[i], o2[i]); }
+            printf("  mismatches %zu of %zu\n", bad, o1.size());
+        }
+        for (int ll = 1; ll <= 4; ++ll) {
+            dim3 gl((N + QB - 1) / QB, ll);
+            char nm[64]; snprintf(nm, 64, "base nt, %d level(s)", ll);
+            printf("%-34s %7.2f us\n", nm, timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL(k_base<32>, gl, block, 0, 0, a); }));
+            snprintf(nm, 64, "no taps nt, %d level(s)", ll);
+            printf("%-34s %7.2f us\n", nm, timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL(k_base<34>, gl, block, 0, 0, a); }));
+        }
+        dim3 g16((N + 15) / 16, L), g32((N + 31) / 32, L);
+        printf("%-34s %7.2f us\n", "lines QB=16", timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL((k_lines<16, 0>), g16, block, 16 * 448 * 4, 0, a); }));
+        printf("%-34s %7.2f us\n", "lines QB=16 nt", timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL((k_lines<16, 32>), g16, block, 16 * 448 * 4, 0, a); }));
+        printf("%-34s %7.2f us\n", "lines QB=32 nt", timeit([&](int i) { a.coords = dco[i % NC]; hipLaunchKernelGGL((k_lines<32, 32>), g32, block, 32 * 448 * 4, 0, a); }));
+    }
+    return 0;
+}
