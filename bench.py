@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from raft_amd import CorrBlock, _lib       # noqa: E402
+from raft_amd.sharding import max_over_ranks   # noqa: E402
 
 # workload: BASELINE.json configs[1]
 IMG_H, IMG_W = 436, 1024
@@ -145,10 +146,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)      # slowest rank defines the job time
 
     build_ms = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
     lookup_ms = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) / ITERS
