@@ -11,13 +11,13 @@
 // operand shape of v_mfma_f32_32x32x2_f32 (lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]), so no transposes anywhere.
 //
-//   pack    F1 -> [M tile][k][128] (zero padded), F2 -> [patch][k][(j, n)] (zero padded):
+//   pack    (one small launch) F1 -> [M tile][k][128], F2 -> [patch][k][(j, n)], zero padded:
 //           tile panels are contiguous, the K loop has no bounds checks and each wave moves
 //           its share with 16-byte direct-to-LDS loads (global_load_lds_dwordx4).
 //   block   256 threads = 4 waves, 128 queries x one 8x16 patch (128 targets)
 //   wave w  32 queries x 128 targets: accumulator n <-> 4x8 tile n of the patch,
 //           MFMA column (lane & 31) <-> cell j of the tile
-//   K loop  BK = 32, two LDS buffers, the DMA of tile k+1 in flight while tile k is multiplied,
+//   K loop  BK = 16, two LDS buffers (32 KB per block, 3 blocks per CU), the DMA of tile k+1 in flight while tile k is multiplied,
 //           one barrier per K tile; B fragments of the four accumulators are one ds_read_b128.
 //   epilog  level 0: every store instruction writes two full 128-B lines (one per lane half);
 //           level 1/2: DPP reductions inside the 16-lane rows (quad_perm, row_half_mirror,
@@ -30,51 +30,65 @@ namespace raftcorr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;      // queries per block
-constexpr int BK = 32;
+constexpr int BK = 16;      // K rows per LDS tile of the shipped instantiation (tools/build_lab.hip:
+                            // BK=16 at 3 waves/SIMD beat BK=32 at 2 and BK=8/16 at 4)
+constexpr int WPS = 3;      // waves per SIMD the register allocation is bounded for
 constexpr int GROUP_M = 8;   // query tiles walked together (L2 reuse of the operand panels)
 
 // ---------------------------------------------------------------------------------------
 // pack: feature maps -> tile-major, zero-padded operand panels
 // ---------------------------------------------------------------------------------------
-// mode 0: dst[b][tile][k][c]           = src[b][k][tile*128 + c]                 (queries)
-// mode 1: dst[b][patch][k][j*4 + n]    = src[b][k][target(patch, n, j)]          (MFMA B operand)
-// mode 2: dst[b][patch][k][n*32 + j]   = src[b][k][target(patch, n, j)]          (volume column order)
+//   F1p[b][tile][k][c]        = F1[b][k][tile*128 + c]                  (queries, linear)
+//   F2p[b][patch][k][j*4 + n] = F2[b][k][target(patch, n, j)]           (MFMA B operand order)
+// One launch for both operands: grid (tilesM + tilesN, PACK_KSPLIT, B); a thread owns one column
+// of one tile and walks its share of the k rows, so source/destination offsets are computed once
+// and both sides are coalesced along the pixel index.
+constexpr int PACK_KSPLIT = 8;
+
+struct PackArgs {
+    const float* f1; const float* f2; float* f1p; float* f2p;
+    int D, Dpad, H, W, tilesM, tilesN;
+};
+
 __global__ __launch_bounds__(256)
-void corr_pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                      int B, int D, int Dpad, int H, int W, int tiles, int mode)
+void corr_pack_kernel(PackArgs p)
 {
-    const int N = H * W;
-    const int PW = patches_w(W);
-    const size_t total = (size_t)B * tiles * Dpad * 128;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e & 127);
-        size_t r = e >> 7;
-        const int k = (int)(r % Dpad); r /= Dpad;
-        const int tile = (int)(r % tiles);
-        const int b = (int)(r / tiles);
-        int t = -1;
-        if (mode == 0) {
-            const int q = tile * 128 + c;
-            if (q < N) t = q;
-        } else {
-            const int n = (mode == 1) ? (c & 3) : (c >> 5);
-            const int j = (mode == 1) ? (c >> 2) : (c & 31);
-            const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
-            const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
-            const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
-            const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
-            if (y < H && x < W) t = y * W + x;
-        }
-        dst[e] = (t >= 0 && k < D) ? src[((size_t)b * D + k) * N + t] : 0.f;
+    const int N = p.H * p.W;
+    const int c = threadIdx.x & 127, kp = threadIdx.x >> 7;
+    const int b = blockIdx.z;
+    int tile = blockIdx.x;
+    const bool second = tile >= p.tilesM;
+    int t = -1;
+    if (!second) {
+        const int q = tile * 128 + c;
+        if (q < N) t = q;
+    } else {
+        tile -= p.tilesM;
+        const int PW = patches_w(p.W);
+        const int n = c & 3, j = c >> 2;
+        const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
+        const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
+        const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
+        const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
+        if (y < p.H && x < p.W) t = y * p.W + x;
+    }
+    const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
+    float* __restrict__ dst = (second ? p.f2p + ((size_t)b * p.tilesN + tile) * p.Dpad * 128
+                                      : p.f1p + ((size_t)b * p.tilesM + tile) * p.Dpad * 128) + c;
+    const int per = p.Dpad / PACK_KSPLIT;                 // Dpad is a multiple of 32
+    const int k0 = blockIdx.y * per + kp;
+#pragma unroll 4
+    for (int i = 0; i < per / 2; ++i) {
+        const int k = k0 + 2 * i;
+        dst[(size_t)k * 128] = (t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f;
     }
 }
 
-int launch_pack(const float* src, float* dst, int B, int D, int Dpad, int H, int W, int tiles, int mode,
-                hipStream_t s)
+int launch_pack_operands(const float* f1, const float* f2, float* f1p, float* f2p, int B, int D, int Dpad,
+                         int H, int W, int tilesM, int tilesN, hipStream_t s)
 {
-    const size_t total = (size_t)B * tiles * Dpad * 128;
-    const unsigned g = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(corr_pack_kernel, dim3(g), dim3(256), 0, s, src, dst, B, D, Dpad, H, W, tiles, mode);
+    PackArgs a{f1, f2, f1p, f2p, D, Dpad, H, W, tilesM, tilesN};
+    hipLaunchKernelGGL(corr_pack_kernel, dim3(tilesM + tilesN, PACK_KSPLIT, B), dim3(256), 0, s, a);
     return check_launch("corr_pack_kernel");
 }
 
@@ -109,8 +123,8 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_chunk)
                                      (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
 }
 
-template <bool EXACT_MUL>
-__global__ __launch_bounds__(256, 2)
+template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD)
 void corr_build_f32_kernel(BuildArgs p)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];   // [buf][A|B][k][128]
@@ -143,15 +157,15 @@ void corr_build_f32_kernel(BuildArgs p)
     const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * Dpad * 128;
     const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * Dpad * 128;
 
-    // stage K tile kt into LDS buffer buf: 16 KB of A + 16 KB of B, 4 + 4 DMA pieces per wave
+    // stage K tile kt into LDS buffer buf: BK x 512 B of A and of B, BK/8 + BK/8 DMA pieces per wave
     auto stage = [&](int kt, int buf) {
         float* la = smem + buf * (2 * BK * 128);
         float* lb = la + BK * 128;
         const float* ga = pa + (size_t)kt * BK * 128;
         const float* gb = pb + (size_t)kt * BK * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;              // 1 KiB pieces, 16 per operand tile
+        for (int i = 0; i < BK / 8; ++i) {
+            const int piece = wave * (BK / 8) + i;       // 1 KiB pieces, BK/2 per operand tile
             glds16(ga + piece * 256 + lane * 4, la + piece * 256);
             glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
         }
@@ -193,6 +207,13 @@ void corr_build_f32_kernel(BuildArgs p)
         }
     }
 
+#if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
+    return;
+#endif
     // ---- epilogue ------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Stores go through buffer descriptors that cover exactly this wave's valid query rows:
@@ -283,7 +304,7 @@ __global__ void pool2x2_kernel(const float* __restrict__ in, float* __restrict__
 size_t build_workspace_bytes(int B, int D, int H, int W)
 {
     const int N = H * W;
-    const size_t Dpad = (size_t)(D + BK - 1) / BK * BK;
+    const size_t Dpad = (size_t)(D + 31) / 32 * 32;
     const size_t tilesM = (N + BM - 1) / BM, tilesN = (size_t)patches_h(H) * patches_w(W);
     return (size_t)B * Dpad * 128 * (tilesM + tilesN) * sizeof(float);
 }
@@ -296,15 +317,13 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
                     workspace_bytes, build_workspace_bytes(B, D, H, W));
     BuildArgs a;
     a.B = B; a.N = H * W; a.L = L < 4 ? L : 4;
-    a.Dpad = (D + BK - 1) / BK * BK;
+    a.Dpad = (D + 31) / 32 * 32;             // multiple of every BK the kernel is instantiated for
     a.tilesM = (a.N + BM - 1) / BM;
     a.tilesN = patches_h(H) * patches_w(W);
     a.nblk_per_b = a.tilesM * a.tilesN;
     float* f1p = (float*)workspace;
     float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * 128;
-    int rc = launch_pack(f1, f1p, B, D, a.Dpad, H, W, a.tilesM, 0, s);
-    if (rc) return rc;
-    rc = launch_pack(f2, f2p, B, D, a.Dpad, H, W, a.tilesN, 1, s);
+    int rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
     if (rc) return rc;
     a.f1p = f1p; a.f2p = f2p;
     for (int l = 0; l < 4; ++l) {
@@ -321,8 +340,8 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     const long long nblk = (long long)a.nblk_per_b * B;
     if (nblk > 0x7fffffffLL) return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: grid too large");
     dim3 grid((unsigned)nblk), block(256);
-    if (exact) hipLaunchKernelGGL(corr_build_f32_kernel<true>, grid, block, 0, s, a);
-    else       hipLaunchKernelGGL(corr_build_f32_kernel<false>, grid, block, 0, s, a);
+    if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);
+    else       hipLaunchKernelGGL((corr_build_f32_kernel<false, BK, WPS>), grid, block, 0, s, a);
     rc = check_launch("corr_build_f32_kernel");
     if (rc) return rc;
     for (int l = 4; l < L; ++l) {

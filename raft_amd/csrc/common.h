@@ -19,8 +19,6 @@ struct LevelSet {                 // by-value kernel argument: per-level pointer
 // launchers (each validates nothing: the extern "C" layer in api.hip does)
 size_t build_workspace_bytes(int B, int D, int H, int W);
 size_t build_bwd_workspace_bytes(int B, int D, int H, int W);
-int launch_pack(const float* src, float* dst, int B, int D, int Dpad, int H, int W, int tiles, int mode,
-                hipStream_t s);
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
                          const LevelSet& lv, void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,

@@ -1,0 +1,58 @@
+// Experiment harness (not product code): times variants of the pyramid build kernel.
+// Compiled twice (with and without -DRC_LAB_SKIP_EPILOGUE) by tools/Makefile.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../raft_amd/csrc/build_pyramid.hip"
+
+namespace raftcorr {
+int fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); return code; }
+int check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return -3; } return 0; }
+}
+using namespace raftcorr;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <typename F> float timeit(F launch, int iters = 30)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv)
+{
+    const int B = 1, D = 256, H = argc > 2 ? atoi(argv[1]) : 55, W = argc > 2 ? atoi(argv[2]) : 128, N = H * W, L = 4;
+    BuildArgs a; a.B = B; a.N = N; a.L = L;
+    a.tilesM = (N + BM - 1) / BM; a.tilesN = patches_h(H) * patches_w(W); a.nblk_per_b = a.tilesM * a.tilesN;
+    a.inv_sqrt_d = 1.f / 16; a.sqrt_d = 16;
+    for (int l = 0; l < 4; ++l) {
+        LevelGeom g = level_geom(H, W, l); a.slab[l] = g.slab;
+        CK(hipMalloc(&a.lvl[l], (size_t)N * g.slab * 4));
+    }
+    std::vector<float> h((size_t)D * N);
+    for (auto& v : h) v = (rand() / (float)RAND_MAX) * 2 - 1;
+    float *f1, *f2, *ws;
+    CK(hipMalloc(&f1, h.size() * 4)); CK(hipMalloc(&f2, h.size() * 4));
+    CK(hipMemcpy(f1, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(f2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ws, build_workspace_bytes(B, D, H, W)));
+    float* f1p = ws; float* f2p = ws + (size_t)B * a.tilesM * D * 128;
+    a.f1p = f1p; a.f2p = f2p; a.Dpad = D;
+    launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
+    dim3 grid(a.nblk_per_b), block(256);
+    const double flops = 2.0 * N * (double)N * D;
+#define RUN(name, ...) { float us = timeit([&]() { hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, 0, a); }); printf("%-40s %8.1f us  %6.1f TF\n", name, us, flops / us * 1e-6); }
+    RUN("BK=32, 2 waves/SIMD (product)", corr_build_f32_kernel<true, 32, 2>);
+    RUN("BK=16, 2 waves/SIMD", corr_build_f32_kernel<true, 16, 2>);
+    RUN("BK=16, 4 waves/SIMD", corr_build_f32_kernel<true, 16, 4>);
+    RUN("BK=16, 3 waves/SIMD", corr_build_f32_kernel<true, 16, 3>);
+    RUN("BK=8, 4 waves/SIMD", corr_build_f32_kernel<true, 8, 4>);
+    printf("pack: %.1f us\n", timeit([&]() { launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0); }));
+    return 0;
+}
