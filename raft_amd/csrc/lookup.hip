@@ -12,12 +12,14 @@
 // (y0 - r + ty, x0 - r + tx) or 0 outside the level (grid_sample's zero padding).
 //
 // A block handles QB = 32 consecutive queries of one level (grid.y = level):
-//   phase 0  32 threads split the coordinates (floor / fraction)          -> LDS
-//   phase 1  all threads gather the 32 x (2r+2)^2 taps.  The kernel is latency-bound (one
-//            block = three dependent memory round trips), so all of a thread's loads are
-//            issued back to back into registers, branch-free (out-of-range taps read a
-//            valid dummy address and are zeroed by a select), with the level's address
-//            arithmetic (patch-tile order, layout.h) resolved at compile time     -> LDS
+//   phase 0  the tap address splits into a y-only and an x-only part (patch-tile order,
+//            layout.h); they are tabulated per (query, window row) / (query, window column),
+//            2 x 32 x (2r+2) entries, each thread loading the coordinate it needs  -> LDS
+//   phase 1  all threads gather the 32 x (2r+2)^2 taps.  The kernel is latency- and
+//            issue-bound (one block = three dependent memory round trips, one wave per
+//            SIMD), so all of a thread's loads are issued back to back into registers,
+//            branch-free (out-of-range taps read a valid dummy address and are zeroed by a
+//            select), offset = ytab + xtab, level kind resolved at compile time    -> LDS
 //   phase 2  all threads blend 4 LDS taps per output and store coalesced: along the
 //            channel dim for the (B,N,C) layout, along the query dim for (B,C,H,W).
 //            Output stores are non-temporal: the result is consumed by another kernel and
@@ -26,6 +28,10 @@
 // filter of dOut, added to d(level) with a plain read-modify-write: a (query, tap) cell
 // belongs to exactly one thread of one block, so no atomics are needed.
 #include "common.h"
+
+#ifndef RC_STAMP            // tools/lookup_lab2.hip defines it for diagnostic (timing-stamp) builds
+#define RC_STAMP(i)
+#endif
 
 namespace raftcorr {
 
@@ -78,9 +84,34 @@ __device__ __forceinline__ int pos_k(int pw, int w, int y, int x)
     return y * w + x;
 }
 
+// pos_k splits into a y-only and an x-only part (the bit fields are disjoint), so a block can
+// tabulate them once per (query, window row) and (query, window column):
+//   pos_k<KIND>(pw, w, y, x) == ypart_k<KIND>(pw, w, y) + xpart_k<KIND>(x)
+template <int KIND>
+__device__ __forceinline__ int ypart_k(int pw, int w, int y)
+{
+    if (KIND == 0) return (y >> 3) * pw * 128 + ((y >> 2) & 1) * 64 + (y & 1) * 2 + ((y >> 1) & 1) * 4;
+    if (KIND == 1) return (y >> 2) * pw * 32 + ((y >> 1) & 1) * 16 + (y & 1);
+    if (KIND == 2) return (y >> 1) * pw * 8 + (y & 1) * 4;
+    if (KIND == 3) return y * pw * 2;
+    return y * w;
+}
+template <int KIND>
+__device__ __forceinline__ int xpart_k(int x)
+{
+    if (KIND == 0) return (x >> 4) * 128 + ((x >> 3) & 1) * 32 + (x & 1) + ((x >> 1) & 1) * 8 + ((x >> 2) & 1) * 16;
+    if (KIND == 1) return (x >> 3) * 32 + ((x >> 2) & 1) * 8 + (x & 1) * 2 + ((x >> 1) & 1) * 4;
+    if (KIND == 2) return (x >> 2) * 8 + ((x >> 1) & 1) * 2 + (x & 1);
+    return x;
+}
+
+constexpr int TAB_INVALID = -(1 << 30);    // marks a window row / column outside the level
+
 struct LookupSmem {
     float* tile;   // fwd: [QB][ST] taps;  bwd: [QB][SG] dOut
-    float* sfx; float* sfy; int* sx0; int* sy0;
+    float* sfx; float* sfy;
+    int* xtab;     // [QB][T]  x part of the tap offset, TAB_INVALID outside
+    int* ytab;     // [QB][T]  y part + query slab offset (relative to the block's first query)
 };
 
 __device__ __forceinline__ LookupSmem carve(float* smem, int r, bool bwd)
@@ -91,23 +122,54 @@ __device__ __forceinline__ LookupSmem carve(float* smem, int r, bool bwd)
     s.tile = smem;
     s.sfx = smem + QB * stride;
     s.sfy = s.sfx + QB;
-    s.sx0 = (int*)(s.sfy + QB);
-    s.sy0 = s.sx0 + QB;
+    s.xtab = (int*)(s.sfy + QB);
+    s.ytab = s.xtab + QB * T;
     return s;
 }
 
-__device__ __forceinline__ void split_block_coords(const LookupArgs& p, const LookupSmem& s, int b, int q0,
-                                                   int l, int r)
+// phase 0: every thread loads the coordinate it needs itself (the 2r+2 lanes of a query hit the
+// same address) and writes one table entry; one barrier later all address parts are in LDS.
+template <int R, int KIND>
+__device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSmem& s, const LevelGeom& g,
+                                             int b, int q0, int l, int r)
 {
-    const int tid = threadIdx.x;
-    if (tid < QB) {
-        const int q = q0 + tid;
-        float x = 0.f, y = 0.f;
-        if (q < p.N) load_xy(p, b, q, l, x, y);
-        int x0, y0; float fx, fy;
-        split_coord(x, x0, fx);
-        split_coord(y, y0, fy);
-        s.sx0[tid] = x0 - r; s.sy0[tid] = y0 - r; s.sfx[tid] = fx; s.sfy[tid] = fy;
+    const int T = 2 * r + 2;
+    auto load_c = [&](int e) -> float {          // coordinate component behind table entry e
+        const bool isy = e >= QB * T;
+        const int ee = isy ? e - QB * T : e;
+        const int q = q0 + min(ee / T, QB - 1);
+        if (q >= p.N || e >= 2 * QB * T) return 0.f;
+        if (p.mode == RAFTCORR_MODE_FORK) return p.coords[((size_t)b * p.N + q) * 2 + (isy ? 1 : 0)];
+        return p.coords[((size_t)b * 2 + (isy ? 1 : 0)) * p.N + q] * (1.0f / (float)(1 << l));
+    };
+    auto emit = [&](int e, float c) {
+        if (e >= 2 * QB * T) return;
+        const bool isy = e >= QB * T;
+        const int ee = isy ? e - QB * T : e;
+        const int qi = ee / T, k = ee - qi * T;
+        int c0; float fc;
+        split_coord(c, c0, fc);
+        const int v = c0 - r + k;
+        if (isy) {
+            const bool ok = q0 + qi < p.N && v >= 0 && v < g.h;
+            s.ytab[ee] = ok ? ypart_k<KIND>(g.pw, g.w, v) + qi * (int)g.slab : TAB_INVALID;
+            if (k == 0) s.sfy[qi] = fc;
+        } else {
+            const bool ok = v >= 0 && v < g.w;
+            s.xtab[ee] = ok ? xpart_k<KIND>(v) : TAB_INVALID;
+            if (k == 0) s.sfx[qi] = fc;
+        }
+    };
+    if (R >= 0) {
+        constexpr int Rc = R >= 0 ? R : 0;
+        constexpr int NTAB = (2 * QB * (2 * Rc + 2) + 255) / 256;
+        float c[NTAB];
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) c[i] = load_c(threadIdx.x + i * 256);     // loads in flight together
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) emit(threadIdx.x + i * 256, c[i]);
+    } else {
+        for (int e = threadIdx.x; e < 2 * QB * T; e += 256) emit(e, load_c(e));
     }
 }
 
@@ -124,51 +186,49 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
     const LevelGeom g = p.lv.g[l];
-    const int Hl = g.h, Wl = g.w;
     const int N = p.N;
-    const float* __restrict__ vol = p.lv.ptr[l] + (size_t)b * N * g.slab;
+    const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
 
-    split_block_coords(p, s, b, q0, l, r);
+    RC_STAMP(0);
+    build_tables<R, KIND>(p, s, g, b, q0, l, r);
     __syncthreads();
+    RC_STAMP(1);
 
     if (R >= 0) {
         constexpr int Rc = R >= 0 ? R : 0;
-        constexpr int NIT = (QB * (2 * Rc + 2) * (2 * Rc + 2) + 255) / 256;
+        constexpr int Tc = 2 * Rc + 2, TTc = Tc * Tc;
+        constexpr int NIT = (QB * TTc + 255) / 256;
         float v[NIT];
-        bool ok[NIT];
+        int off[NIT];
+        int qi = tid / TTc, t = tid - qi * TTc;   // tap e = tid + 256*i, walked incrementally
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + i * 256;
-            const int qe = e / TT;
-            const int qi = min(qe, QB - 1);
-            const int t = e - qe * TT;
-            const int ty = t / T, tx = t - ty * T;
-            const int q = q0 + qi;
-            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
-            ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl;
-            const int pos = ok[i] ? pos_k<KIND>(g.pw, Wl, yi, xi) : 0;
-            v[i] = vol[(size_t)(ok[i] ? q : 0) * g.slab + pos];
+            const int qc = min(qi, QB - 1);
+            const int ty = t / Tc, tx = t - ty * Tc;
+            const int o = s.ytab[qc * Tc + ty] + s.xtab[qc * Tc + tx];
+            off[i] = (qi < QB && o >= 0) ? o : -1;
+            v[i] = vol[max(o, 0)];                // invalid taps read a valid dummy address
+            t += 256 % TTc; qi += 256 / TTc;
+            if (t >= TTc) { t -= TTc; ++qi; }
         }
+        qi = tid / TTc; t = tid - qi * TTc;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + i * 256;
-            const int qe = e / TT;
-            if (e < QB * TT) taps[qe * ST + (e - qe * TT)] = ok[i] ? v[i] : 0.f;
+            if (qi < QB) taps[qi * ST + t] = off[i] >= 0 ? v[i] : 0.f;
+            t += 256 % TTc; qi += 256 / TTc;
+            if (t >= TTc) { t -= TTc; ++qi; }
         }
     } else {
         for (int e = tid; e < QB * TT; e += 256) {
             const int qi = e / TT;
             const int t = e - qi * TT;
             const int ty = t / T, tx = t - ty * T;
-            const int q = q0 + qi;
-            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
-            float v = 0.f;
-            if (q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)
-                v = vol[(size_t)q * g.slab + pos_k<KIND>(g.pw, Wl, yi, xi)];
-            taps[qi * ST + t] = v;
+            const int o = s.ytab[qi * T + ty] + s.xtab[qi * T + tx];
+            taps[qi * ST + t] = o >= 0 ? vol[o] : 0.f;
         }
     }
     __syncthreads();
+    RC_STAMP(2);
 
     const int C = p.L * rd2;
     if (p.mode == RAFTCORR_MODE_FORK) {
@@ -194,14 +254,35 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
         const float fx = s.sfx[qi], fy = s.sfy[qi];
         const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
         const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-        for (int ch = tid / QB; ch < rd2; ch += 256 / QB) {
-            const int a = ch / rd;
-            const int bb = ch - a * rd;
-            const float* tp = taps + qi * ST + bb * T + a;
-            const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
-            if (vq) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]);
+        const float* tq = taps + qi * ST;
+        if (R >= 0) {
+            constexpr int Rc = R >= 0 ? R : 0;
+            constexpr int rdc = 2 * Rc + 1, Tc = 2 * Rc + 2;
+            constexpr int NOUT = (rdc * rdc + 7) / 8;
+            float o[NOUT];
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) {      // all LDS reads of the thread in flight together
+                const int ch = min(tid / QB + i * 8, rdc * rdc - 1);
+                const int a = ch / rdc, bb = ch - a * rdc;
+                const float* tp = tq + bb * Tc + a;
+                o[i] = tp[0] * w00 + tp[1] * w01 + tp[Tc] * w10 + tp[Tc + 1] * w11;
+            }
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) {
+                const int ch = tid / QB + i * 8;
+                if (vq && ch < rdc * rdc) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
+            }
+        } else {
+            for (int ch = tid / QB; ch < rd2; ch += 256 / QB) {
+                const int a = ch / rd;
+                const int bb = ch - a * rd;
+                const float* tp = tq + bb * T + a;
+                const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
+                if (vq) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]);
+            }
         }
     }
+    RC_STAMP(3);
 }
 
 template <int R>
@@ -231,12 +312,11 @@ __device__ __forceinline__ void lookup_bwd_body(const LookupArgs& p, float* smem
     const int q0 = blockIdx.x * QB;
     const int tid = threadIdx.x;
     const LevelGeom geo = p.dlv.g[l];
-    const int Hl = geo.h, Wl = geo.w;
     const int N = p.N;
-    float* __restrict__ dvol = p.dlv.ptr[l] + (size_t)b * N * geo.slab;
+    float* __restrict__ dvol = p.dlv.ptr[l] + ((size_t)b * N + q0) * geo.slab;     // block's first slab
     const int C = p.L * rd2;
 
-    split_block_coords(p, s, b, q0, l, r);
+    build_tables<R, KIND>(p, s, geo, b, q0, l, r);
     if (p.mode == RAFTCORR_MODE_FORK) {
         const float* __restrict__ d = p.dout + ((size_t)b * N + q0) * C + l * rd2;
         for (int e = tid; e < QB * rd2; e += 256) {
@@ -266,43 +346,36 @@ __device__ __forceinline__ void lookup_bwd_body(const LookupArgs& p, float* smem
 
     if (R >= 0) {
         constexpr int Rc = R >= 0 ? R : 0;
-        constexpr int NIT = (QB * (2 * Rc + 2) * (2 * Rc + 2) + 255) / 256;
+        constexpr int Tc = 2 * Rc + 2, TTc = Tc * Tc;
+        constexpr int NIT = (QB * TTc + 255) / 256;
         float old[NIT];
-        size_t off[NIT];
-        bool ok[NIT];
+        int off[NIT];
+        int qi = tid / TTc, t = tid - qi * TTc;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {          // all read-modify-write loads in flight together
-            const int e = tid + i * 256;
-            const int qe = e / TT;
-            const int qi = min(qe, QB - 1);
-            const int t = e - qe * TT;
-            const int ty = t / T, tx = t - ty * T;
-            const int q = q0 + qi;
-            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
-            ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl;
-            const int pos = ok[i] ? pos_k<KIND>(geo.pw, Wl, yi, xi) : 0;
-            off[i] = (size_t)(ok[i] ? q : 0) * geo.slab + pos;
-            old[i] = dvol[off[i]];
+            const int qc = min(qi, QB - 1);
+            const int ty = t / Tc, tx = t - ty * Tc;
+            const int o = s.ytab[qc * Tc + ty] + s.xtab[qc * Tc + tx];
+            off[i] = (qi < QB && o >= 0) ? o : -1;
+            old[i] = dvol[max(o, 0)];
+            t += 256 % TTc; qi += 256 / TTc;
+            if (t >= TTc) { t -= TTc; ++qi; }
         }
+        qi = tid / TTc; t = tid - qi * TTc;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + i * 256;
-            const int qe = e / TT;
-            const int qi = min(qe, QB - 1);
-            const int t = e - qe * TT;
-            const int ty = t / T, tx = t - ty * T;
-            if (ok[i]) dvol[off[i]] = old[i] + tap_grad(qi, tx, ty);
+            const int ty = t / Tc, tx = t - ty * Tc;
+            if (off[i] >= 0) dvol[off[i]] = old[i] + tap_grad(qi, tx, ty);
+            t += 256 % TTc; qi += 256 / TTc;
+            if (t >= TTc) { t -= TTc; ++qi; }
         }
     } else {
         for (int e = tid; e < QB * TT; e += 256) {
             const int qi = e / TT;
             const int t = e - qi * TT;
             const int ty = t / T, tx = t - ty * T;
-            const int q = q0 + qi;
-            const int xi = s.sx0[qi] + tx, yi = s.sy0[qi] + ty;
-            if (!(q < N && xi >= 0 && xi < Wl && yi >= 0 && yi < Hl)) continue;
-            float* d = dvol + (size_t)q * geo.slab + pos_k<KIND>(geo.pw, Wl, yi, xi);
-            *d += tap_grad(qi, tx, ty);
+            const int o = s.ytab[qi * T + ty] + s.xtab[qi * T + tx];
+            if (o >= 0) dvol[o] += tap_grad(qi, tx, ty);
         }
     }
 }
@@ -376,7 +449,7 @@ static size_t lookup_smem(int r, bool bwd)
 {
     const int T = 2 * r + 2, rd = 2 * r + 1;
     const int stride = bwd ? ((rd * rd) | 1) : ((T * T) | 1);
-    return sizeof(float) * ((size_t)QB * stride + 4 * QB);
+    return sizeof(float) * ((size_t)QB * stride + 2 * QB + 2 * QB * T);
 }
 
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,

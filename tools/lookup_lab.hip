@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 #include "../raft_amd/csrc/layout.h"
 using namespace raftcorr;
 
@@ -161,9 +162,14 @@ template <int KIND> __device__ __forceinline__ int pos_k(int pw, int w, int y, i
     return y * w + x;
 }
 
+__device__ unsigned* g_xcc;
+__device__ unsigned long long* g_stamps;   // [blocks][4], diagnostic builds only
+#define STAMP(i) do { if ((FLAGS & 64) && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = t_; } } while (0)
 template <int KIND, int FLAGS>
 __device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, float* sfy, int* sx0, int* sy0)
 {
+    STAMP(0);
+    if ((FLAGS & 64) && threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_xcc[blockIdx.y * gridDim.x + blockIdx.x] = xcc & 0xf; }
     const int l = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x, N = p.N;
     const LevelGeom g = p.g[l];
     const float* __restrict__ vol = p.lvl[l];
@@ -176,6 +182,7 @@ __device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, fl
         sx0[tid] = (int)fx0 - R; sy0[tid] = (int)fy0 - R; sfx[tid] = x - fx0; sfy[tid] = y - fy0;
     }
     __syncthreads();
+    STAMP(1);
     {
         constexpr int NIT = (QB * TT + 255) / 256;
         float v[NIT];
@@ -187,7 +194,7 @@ __device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, fl
             const int q = q0 + qi, xi = sx0[qi] + tx, yi = sy0[qi] + ty;
             ok[i] = (e < QB * TT) && q < N && xi >= 0 && xi < g.w && yi >= 0 && yi < g.h;
             const int pos = ok[i] ? pos_k<KIND>(g.pw, g.w, yi, xi) : 0;
-            v[i] = vol[(size_t)(ok[i] ? q : 0) * g.slab + pos];
+            v[i] = vol[(size_t)(ok[i] ? ((FLAGS & 16) ? (q & 63) : q) : 0) * g.slab + pos];
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -196,11 +203,35 @@ __device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, fl
         }
     }
     __syncthreads();
+    STAMP(2);
     float* __restrict__ out = p.out + (size_t)(l * RD2) * N + q0;
     const int qi = tid & (QB - 1);
     const bool vq = q0 + qi < N;
     const float fx = sfx[qi], fy = sfy[qi];
     const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    if (FLAGS & 128) {
+        // thread <-> (channel, 4 consecutive queries): one 16-byte write-through (sc1) store each
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.L * RD2 * N * 4), 0x00020000);
+        for (int e = tid; e < RD2 * (QB / 4); e += 256) {
+            const int gq = e & 7, ch = e >> 3;
+            const int a = ch / RD, bb = ch - a * RD;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int qq = gq * 4 + k;
+                const float fxx = sfx[qq], fyy = sfy[qq];
+                const float* tp = taps + qq * ST + bb * T + a;
+                o[k] = tp[0] * ((1.f - fxx) * (1.f - fyy)) + tp[1] * (fxx * (1.f - fyy)) + tp[T] * ((1.f - fxx) * fyy) + tp[T + 1] * (fxx * fyy);
+            }
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            f4 vv = {o[0], o[1], o[2], o[3]};
+            const unsigned off = (unsigned)(((size_t)(l * RD2 + ch) * N + q0 + gq * 4) * 4);
+            if (q0 + gq * 4 + 3 < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, vv), rs, off, 0, 16);
+        }
+        if (FLAGS & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < (RD2 + 7) / 8; ++i) {
         const int ch = tid / QB + i * 8;
@@ -211,6 +242,7 @@ __device__ __forceinline__ void body2(const Args& p, float* taps, float* sfx, fl
             if (vq) { if (FLAGS & 32) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]); else out[(size_t)ch * N + qi] = o; }
         }
     }
+    if (FLAGS & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
 }
 
 template <int FLAGS>
@@ -240,6 +272,9 @@ template <typename F> float timeit(F launch, int iters = 200)
     return ms * 1e3f / iters;
 }
 
+#ifndef STAMPV
+#define STAMPV 96
+#endif
 int main()
 {
     const int H = 55, W = 128, N = H * W, L = 4, NC = 32;
@@ -282,6 +317,33 @@ int main()
         }
         RUN("v2 (kind-templated, branch-free)", k_v2<0>);
         RUN("v2 nt", k_v2<32>);
+        RUN("v2 sc1 x4 stores", k_v2<128>);
+        {   // in-kernel stamps (diagnostic build): where a block's time goes
+            const int nb = grid.x * grid.y;
+            unsigned long long* ds; CK(hipMalloc(&ds, nb * 4 * 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ds, sizeof(ds)));
+            unsigned* dx; CK(hipMalloc(&dx, nb * 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcc), &dx, sizeof(dx)));
+            std::vector<unsigned> prev;
+            auto stamp_run = [&](const char* name, auto kern, dim3 gr) {
+                const int nbb = gr.x * gr.y;
+                for (int rep = 0; rep < 2; ++rep) {
+                    for (int i = 0; i < 5; ++i) { a.coords = dco[i]; hipLaunchKernelGGL(kern, gr, block, 0, 0, a); }
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> hs(nbb * 4);
+                    CK(hipMemcpy(hs.data(), ds, nbb * 4 * 8, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, t3 = 0;
+                    for (int i = 0; i < nbb; ++i) { t0 = std::min(t0, hs[i * 4]); t3 = std::max(t3, hs[i * 4 + 3]); }
+                    double sm[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < nbb; ++i) for (int k = 0; k < 4; ++k) { double v = (hs[i * 4 + k] - t0) * 0.01; sm[k] += v; mx[k] = fmax(mx[k], v); }
+                    printf("%-28s coords avg %.2f max %.2f | taps avg %.2f max %.2f | stores avg %.2f max %.2f | span %.2f\n", name,
+                           sm[1] / nbb, mx[1], sm[2] / nbb, mx[2], sm[3] / nbb, mx[3], (t3 - t0) * 0.01);
+                }
+            };
+            stamp_run("stamps 4 levels", k_v2<192>, grid);
+            stamp_run("stamps 4 levels L2-resident", k_v2<208>, grid);
+            stamp_run("stamps 1 level", k_v2<192>, dim3(grid.x, 1));
+            stamp_run("stamps 1 level L2-resident", k_v2<208>, dim3(grid.x, 1));
+        }
         {   // correctness of v2 vs base
             std::vector<float> o1((size_t)L * RD2 * N), o2(o1.size());
             a.coords = dco[7];
