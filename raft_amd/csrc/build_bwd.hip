@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct FoldArgs {
     float* d0; const float* d1; const float* d2; const float* d3;
     long long s0, s1, s2, s3;
-    int L;
+    int L, PW;
     size_t BN;          // B * N query slabs
     float scale;        // 1/sqrt(D)
     float sqrt_d;
@@ -34,9 +34,14 @@ void corr_fold_levels_kernel(FoldArgs p)
         const int c = (int)(e - qb * p.s0);
         const int patch = c >> 7, n = (c >> 5) & 3, j = c & 31;
         float g = p.d0[e];
-        if (p.L > 1) g += 0.25f * p.d1[qb * p.s1 + patch * 32 + n * 8 + (j >> 2)];
-        if (p.L > 2) g += 0.0625f * p.d2[qb * p.s2 + patch * 8 + n * 2 + (j >> 4)];
-        if (p.L > 3) g += 0.015625f * p.d3[qb * p.s3 + patch * 2 + (n & 1)];
+        // parents in the pooled levels (layout.h): j bits 2,3,4 = dy1, dx1, dx2
+        const int dy1 = (j >> 2) & 1, dx1 = (j >> 3) & 1, dx2 = (j >> 4) & 1;
+        if (p.L > 1) g += 0.25f * p.d1[qb * p.s1 + patch * 32 + n * 8 + (dx1 | (dy1 << 1) | (dx2 << 2))];
+        if (p.L > 2) g += 0.0625f * p.d2[qb * p.s2 + patch * 8 + (dx2 | ((n >> 1) << 1) | ((n & 1) << 2))];
+        if (p.L > 3) {
+            const int ph = patch / p.PW, pwi = patch - ph * p.PW;
+            g += 0.015625f * p.d3[qb * p.s3 + ((ph >> 1) * p.PW + pwi) * 4 + (n & 1) + (ph & 1) * 2];
+        }
         p.d0[e] = p.exact ? g * p.scale : g / p.sqrt_d;
     }
 }
@@ -216,7 +221,7 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     const int Lf = L < 4 ? L : 4;
     f.d0 = dlv.ptr[0]; f.d1 = dlv.ptr[1]; f.d2 = dlv.ptr[2]; f.d3 = dlv.ptr[3];
     f.s0 = dlv.g[0].slab; f.s1 = dlv.g[1].slab; f.s2 = dlv.g[2].slab; f.s3 = dlv.g[3].slab;
-    f.L = Lf; f.BN = BN;
+    f.L = Lf; f.BN = BN; f.PW = patches_w(W);
     const float sq = sqrtf((float)D);
     int e; const float mant = frexpf(sq, &e);
     f.exact = (mant == 0.5f) && (sq * sq == (float)D);

@@ -101,7 +101,7 @@ struct BuildArgs {
     float* lvl[4];
     long long slab[4];    // elements per query slab, levels 0..3
     int B, Dpad, N, L;
-    int tilesM, tilesN, nblk_per_b;
+    int tilesM, tilesN, nblk_per_b, PW;
     float inv_sqrt_d;     // used when sqrt(D) is a power of two (exact)
     float sqrt_d;         // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
 };
@@ -238,9 +238,13 @@ void corr_build_f32_kernel(BuildArgs p)
     const unsigned s0b = (unsigned)(p.slab[0] * 4), s1b = (unsigned)(p.slab[1] * 4);
     const unsigned s2b = (unsigned)(p.slab[2] * 4), s3b = (unsigned)(p.slab[3] * 4);
     const unsigned c0 = (unsigned)(tn * 128 + l31) * 4;                       // + n*128 bytes
-    const unsigned c1 = (unsigned)(tn * 32 + (lane & 3) * 8 + ((lane >> 2) & 7)) * 4;
-    const unsigned c2 = ((lane & 15) < 4) ? (unsigned)(tn * 8 + (lane & 15) * 2 + ((lane >> 4) & 1)) * 4 : OOB;
-    const unsigned c3 = ((lane & 31) < 2) ? (unsigned)(tn * 2 + (lane & 31)) * 4 : OOB;
+    // pooled-cell offsets (layout.h): lane bits b2 = dy1, b3 = dx1, b4 = dx2 of the level-0 cell
+    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1;
+    const unsigned c1 = (unsigned)(tn * 32 + (lane & 3) * 8 + (b3 | (b2 << 1) | (b4 << 2))) * 4;   // quad lane = n
+    const int n2 = lane & 15;                                                                     // row lane = n
+    const unsigned c2 = (n2 < 4) ? (unsigned)(tn * 8 + (b4 | ((n2 >> 1) << 1) | ((n2 & 1) << 2))) * 4 : OOB;
+    const int ph = tn / p.PW, pwi = tn - ph * p.PW;
+    const unsigned c3 = ((lane & 31) < 2) ? (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + (lane & 31) + (ph & 1) * 2) * 4 : OOB;
     const int quad = lane & 3, l15 = lane & 15;
 
 #pragma unroll
@@ -320,6 +324,7 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     a.Dpad = (D + 31) / 32 * 32;             // multiple of every BK the kernel is instantiated for
     a.tilesM = (a.N + BM - 1) / BM;
     a.tilesN = patches_h(H) * patches_w(W);
+    a.PW = patches_w(W);
     a.nblk_per_b = a.tilesM * a.tilesN;
     float* f1p = (float*)workspace;
     float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * 128;

@@ -13,11 +13,13 @@
 // j is also the MFMA column (lane & 31) that produces the cell: the 2x2 pooling partners are
 // lanes xor 1 / xor 2 (one DPP quad), the 4x4 partners are the rest of a 16-lane DPP row.
 //
-// Pooled levels keep the patch order and shrink with it:
-//   level 1: 32 cells per patch (4x8, one line):  pos1 = patch*32 + n*8 + (dy1 | dx1<<1 | dx2<<2)
-//   level 2:  8 cells per patch (2x4):            pos2 = patch*8  + n*2 + dx2
-//   level 3:  2 cells per patch (1x2):            pos3 = patch*2  + (n & 1)
-// with n / dx / dy taken from the level-0 coordinates of the block's top-left cell.
+// Pooled levels keep the patch order and shrink with it; inside a patch the cells are ordered so
+// that EVERY even-aligned 2x2 block of cells of EVERY level is 16 contiguous, 16-byte aligned
+// bytes with inner order (x&1) | (y&1)<<1 -- a lookup fetches four taps with one load:
+//   level 1: 32 cells per patch (4x8, one line):  pos1 = patch*32 + n*8 + (x&1 | (y&1)<<1 | ((x>>1)&1)<<2)
+//   level 2:  8 cells per patch (2x4):            pos2 = patch*8  + (x&1 | (y&1)<<1 | ((x>>1)&1)<<2)
+//   level 3:  2 cells per patch (1x2), patch rows paired: pos3 = ((y>>1)*PW + (x>>1))*4 + (x&1) + (y&1)*2
+// (x, y = the level's own cell coordinates; n as at level 0 from the block's top-left cell).
 // Levels >= 4 (not used by RAFT) are plain row-major H_l x W_l.
 //
 // Cells of the padding (beyond H_l x W_l) hold finite don't-care values and are never read.
@@ -55,7 +57,8 @@ RC_HD LevelGeom level_geom(int H, int W, int l)
         const int np = patches_h(H) * patches_w(W);
         g.pw = patches_w(W);
         g.kind = l;
-        g.slab = (int64_t)np * (PATCH_CELLS >> (2 * l));
+        g.slab = l < 3 ? (int64_t)np * (PATCH_CELLS >> (2 * l))
+                       : (int64_t)((patches_h(H) + 1) >> 1) * patches_w(W) * 4;
     } else {
         g.pw = 0; g.kind = 4;
         g.slab = (int64_t)g.h * g.w;
@@ -77,15 +80,14 @@ RC_HD int level_pos(const LevelGeom& g, int y, int x)
     case 1: {
         const int patch = (y >> 2) * g.pw + (x >> 3);
         const int n = (((y >> 1) & 1) << 1) | ((x >> 2) & 1);
-        return patch * 32 + n * 8 + ((y & 1) | ((x & 1) << 1) | (((x >> 1) & 1) << 2));
+        return patch * 32 + n * 8 + ((x & 1) | ((y & 1) << 1) | (((x >> 1) & 1) << 2));
     }
     case 2: {
         const int patch = (y >> 1) * g.pw + (x >> 2);
-        const int n = ((y & 1) << 1) | ((x >> 1) & 1);
-        return patch * 8 + n * 2 + (x & 1);
+        return patch * 8 + ((x & 1) | ((y & 1) << 1) | (((x >> 1) & 1) << 2));
     }
     case 3:
-        return (y * g.pw + (x >> 1)) * 2 + (x & 1);
+        return ((y >> 1) * g.pw + (x >> 1)) * 4 + (x & 1) + (y & 1) * 2;
     default:
         return y * g.w + x;
     }

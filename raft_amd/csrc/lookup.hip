@@ -73,13 +73,12 @@ __device__ __forceinline__ int pos_k(int pw, int w, int y, int x)
     } else if (KIND == 1) {
         const int patch = (y >> 2) * pw + (x >> 3);
         const int n = (((y >> 1) & 1) << 1) | ((x >> 2) & 1);
-        return patch * 32 + n * 8 + ((y & 1) | ((x & 1) << 1) | (((x >> 1) & 1) << 2));
+        return patch * 32 + n * 8 + ((x & 1) | ((y & 1) << 1) | (((x >> 1) & 1) << 2));
     } else if (KIND == 2) {
         const int patch = (y >> 1) * pw + (x >> 2);
-        const int n = ((y & 1) << 1) | ((x >> 1) & 1);
-        return patch * 8 + n * 2 + (x & 1);
+        return patch * 8 + ((x & 1) | ((y & 1) << 1) | (((x >> 1) & 1) << 2));
     } else if (KIND == 3) {
-        return (y * pw + (x >> 1)) * 2 + (x & 1);
+        return ((y >> 1) * pw + (x >> 1)) * 4 + (x & 1) + (y & 1) * 2;
     }
     return y * w + x;
 }
@@ -91,17 +90,18 @@ template <int KIND>
 __device__ __forceinline__ int ypart_k(int pw, int w, int y)
 {
     if (KIND == 0) return (y >> 3) * pw * 128 + ((y >> 2) & 1) * 64 + (y & 1) * 2 + ((y >> 1) & 1) * 4;
-    if (KIND == 1) return (y >> 2) * pw * 32 + ((y >> 1) & 1) * 16 + (y & 1);
-    if (KIND == 2) return (y >> 1) * pw * 8 + (y & 1) * 4;
-    if (KIND == 3) return y * pw * 2;
+    if (KIND == 1) return (y >> 2) * pw * 32 + ((y >> 1) & 1) * 16 + (y & 1) * 2;
+    if (KIND == 2) return (y >> 1) * pw * 8 + (y & 1) * 2;
+    if (KIND == 3) return (y >> 1) * pw * 4 + (y & 1) * 2;
     return y * w;
 }
 template <int KIND>
 __device__ __forceinline__ int xpart_k(int x)
 {
     if (KIND == 0) return (x >> 4) * 128 + ((x >> 3) & 1) * 32 + (x & 1) + ((x >> 1) & 1) * 8 + ((x >> 2) & 1) * 16;
-    if (KIND == 1) return (x >> 3) * 32 + ((x >> 2) & 1) * 8 + (x & 1) * 2 + ((x >> 1) & 1) * 4;
-    if (KIND == 2) return (x >> 2) * 8 + ((x >> 1) & 1) * 2 + (x & 1);
+    if (KIND == 1) return (x >> 3) * 32 + ((x >> 2) & 1) * 8 + (x & 1) + ((x >> 1) & 1) * 4;
+    if (KIND == 2) return (x >> 2) * 8 + (x & 1) + ((x >> 1) & 1) * 4;
+    if (KIND == 3) return (x >> 1) * 4 + (x & 1);
     return x;
 }
 

@@ -43,12 +43,22 @@ def test_level_layout_matches_avg_pool_floor_and_is_a_bijection():
             assert len(np.unique(pos)) == h * w and (h * w == 0 or (pos.min() >= 0 and pos.max() < slab))
         if L >= 4:      # pooled cells sit where the build kernel's epilogue and the fold put them
             p = [_lib.level_positions(H, W, l).reshape(H >> l, W >> l) for l in range(4)]
+            PW = (W + 15) // 16
             for y in range(0, (H >> 3) << 3, 3):
                 for xx in range(0, (W >> 3) << 3, 5):
                     c = int(p[0][y, xx]); patch, n, j = c >> 7, (c >> 5) & 3, c & 31
-                    assert patch * 32 + n * 8 + (j >> 2) == p[1][y // 2, xx // 2]
-                    assert patch * 8 + n * 2 + (j >> 4) == p[2][y // 4, xx // 4]
-                    assert patch * 2 + (n & 1) == p[3][y // 8, xx // 8]
+                    dy1, dx1, dx2 = (j >> 2) & 1, (j >> 3) & 1, (j >> 4) & 1
+                    ph, pwi = divmod(patch, PW)
+                    assert patch * 32 + n * 8 + (dx1 | dy1 << 1 | dx2 << 2) == p[1][y // 2, xx // 2]
+                    assert patch * 8 + (dx2 | (n >> 1) << 1 | (n & 1) << 2) == p[2][y // 4, xx // 4]
+                    assert ((ph >> 1) * PW + pwi) * 4 + (n & 1) + (ph & 1) * 2 == p[3][y // 8, xx // 8]
+            for l in range(4):      # every even-aligned 2x2 block = 4 consecutive, 16-byte aligned cells
+                h, w = H >> l, W >> l
+                for y in range(0, h - 1, 2):
+                    for xx in range(0, w - 1, 2):
+                        b = int(p[l][y, xx])
+                        assert b % 4 == 0
+                        assert [int(p[l][y, xx + 1]), int(p[l][y + 1, xx]), int(p[l][y + 1, xx + 1])] == [b + 1, b + 2, b + 3]
 
 
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
