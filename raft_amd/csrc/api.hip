@@ -32,10 +32,10 @@ static int make_levels(const char* who, const float* const* ptrs, int H, int W, 
     if (L < 1 || L > RAFTCORR_MAX_LEVELS)
         return fail(RAFTCORR_EINVAL, "%s: num_levels = %d not in [1, %d]", who, L, RAFTCORR_MAX_LEVELS);
     if (!ptrs) return fail(RAFTCORR_EINVAL, "%s: null level pointer array", who);
-    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.g[l] = LevelGeom{0, 0, 0, 4, 0}; }
+    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.g[l] = LevelGeom{0, 0, 0, 0, 0, 4, 0}; }
     for (int l = 0; l < L; ++l) {
         if (volume) lv.g[l] = level_geom(H, W, l);
-        else { lv.g[l].h = H >> l; lv.g[l].w = W >> l; lv.g[l].pw = 0; lv.g[l].kind = 4;
+        else { lv.g[l].h = lv.g[l].hp = H >> l; lv.g[l].w = lv.g[l].wp = W >> l; lv.g[l].pw = 0; lv.g[l].kind = 4;
                lv.g[l].slab = (int64_t)(H >> l) * (W >> l); }
         lv.ptr[l] = const_cast<float*>(ptrs[l]);
         if (!ptrs[l] && lv.g[l].h > 0 && lv.g[l].w > 0)

@@ -41,6 +41,7 @@ constexpr int FUSED_LEVELS = 4;                  // levels produced in patch-til
 
 struct LevelGeom {
     int h, w;        // logical size of the level
+    int hp, wp;      // allocated (padded) size of the level, both even for kinds 0..3
     int pw;          // patches per patch-row (level 0 geometry), 0 for row-major levels
     int kind;        // 0..3: patch-tile order of that level; 4: row-major
     int64_t slab;    // elements per query slab
@@ -57,10 +58,12 @@ RC_HD LevelGeom level_geom(int H, int W, int l)
         const int np = patches_h(H) * patches_w(W);
         g.pw = patches_w(W);
         g.kind = l;
+        g.hp = l < 3 ? (patches_h(H) * PATCH_H) >> l : ((patches_h(H) + 1) >> 1) * 2;
+        g.wp = (patches_w(W) * PATCH_W) >> l;
         g.slab = l < 3 ? (int64_t)np * (PATCH_CELLS >> (2 * l))
                        : (int64_t)((patches_h(H) + 1) >> 1) * patches_w(W) * 4;
     } else {
-        g.pw = 0; g.kind = 4;
+        g.pw = 0; g.kind = 4; g.hp = g.h; g.wp = g.w;
         g.slab = (int64_t)g.h * g.w;
     }
     return g;

@@ -173,6 +173,176 @@ __device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSm
     }
 }
 
+// ---- forward, fused levels (kinds 0..3), compile-time radius ---------------------------------
+// The window's (2r+2)^2 taps are fetched as even-aligned 2x2 blocks: layout.h makes every such
+// block of every fused level one 16-byte aligned float4 (inner order x&1 | (y&1)<<1), so a
+// 10x10 window costs 36 loads and address computations instead of 100.  Per query the blocks
+// cover a TW x TW = (2r+4)^2 cell tile starting at the even-aligned origin; the window sits at
+// parity offset (px, py) inside it.
+template <int R>
+struct BlockGeom {
+    static constexpr int T = 2 * R + 2;          // taps per window side
+    static constexpr int NB = T / 2 + 1;         // 2x2 blocks per tile side
+    static constexpr int TW = 2 * NB;            // tile side in cells
+    static constexpr int STQ = (TW * TW) | 1;    // LDS stride per query (odd: conflict-free)
+    static constexpr int RD = 2 * R + 1;
+};
+
+template <int R>
+__device__ __forceinline__ size_t fwd4_smem_floats()
+{
+    typedef BlockGeom<R> G;
+    return (size_t)QB * G::STQ + 2 * QB * G::NB + 5 * QB;
+}
+
+template <int R, int KIND>
+__device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem)
+{
+    typedef BlockGeom<R> G;
+    float* tile = smem;                                  // [QB][STQ]
+    int* bxtab = (int*)(smem + QB * G::STQ);             // [QB][NB] x part of the block offset
+    int* bytab = bxtab + QB * G::NB;                     // [QB][NB] y part + query slab offset
+    float* sfx = (float*)(bytab + QB * G::NB);
+    float* sfy = sfx + QB;
+    int* xmask = (int*)(sfy + QB);                       // validity bits of the TW tile columns
+    int* ymask = xmask + QB;                             // validity bits of the TW tile rows
+    int* spar = ymask + QB;                              // px | py << 1
+
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB;
+    const int tid = threadIdx.x;
+    const LevelGeom g = p.lv.g[l];
+    const int N = p.N;
+    const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
+
+    RC_STAMP(0);
+    {   // phase 0: block-offset tables, masks, fractions
+        constexpr int NENT = 2 * QB * G::NB;
+        constexpr int NTAB = (NENT + 255) / 256;
+        float c[NTAB];
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) {
+            const int e = tid + i * 256;
+            const bool isy = e >= QB * G::NB;
+            const int ee = isy ? e - QB * G::NB : e;
+            const int q = q0 + min(ee / G::NB, QB - 1);
+            c[i] = 0.f;
+            if (q < N && e < NENT) {
+                if (p.mode == RAFTCORR_MODE_FORK) c[i] = p.coords[((size_t)b * N + q) * 2 + (isy ? 1 : 0)];
+                else c[i] = p.coords[((size_t)b * 2 + (isy ? 1 : 0)) * N + q] * (1.0f / (float)(1 << l));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) {
+            const int e = tid + i * 256;
+            if (e >= NENT) continue;
+            const bool isy = e >= QB * G::NB;
+            const int ee = isy ? e - QB * G::NB : e;
+            const int qi = ee / G::NB, k = ee - qi * G::NB;
+            int c0; float fc;
+            split_coord(c[i], c0, fc);
+            const int cs = c0 - R;                       // first tap of the window
+            const int ca = cs & ~1;                      // even-aligned tile origin
+            const int v = ca + 2 * k;                    // first cell of block k
+            const int dim = isy ? g.h : g.w, dimp = isy ? g.hp : g.wp;
+            const bool ok = v >= 0 && v < dimp && (!isy || q0 + qi < N);
+            if (isy) bytab[ee] = ok ? ypart_k<KIND>(g.pw, g.w, v) + qi * (int)g.slab : TAB_INVALID;
+            else     bxtab[ee] = ok ? xpart_k<KIND>(v) : TAB_INVALID;
+            if (k == 0) {
+                const int lo = max(0, -ca), hi = min(G::TW, dim - ca);       // valid cells: [lo, hi)
+                const int m = hi > lo ? (((1 << hi) - 1) & ~((1 << lo) - 1)) : 0;
+                if (isy) { ymask[qi] = m; sfy[qi] = fc; atomicOr(&spar[qi], (cs & 1) << 1); }
+                else     { xmask[qi] = m; sfx[qi] = fc; atomicOr(&spar[qi], cs & 1); }
+            }
+        }
+    }
+    __syncthreads();
+    RC_STAMP(1);
+
+    {   // phase 1: 2x2 blocks -> LDS tile, all loads of a thread in flight together
+        constexpr int NBLK = G::NB * G::NB;
+        constexpr int NIT = (QB * NBLK + 255) / 256;
+        float4 v[NIT];
+        int off[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            const int qi = min(e / NBLK, QB - 1), blk = e - (e / NBLK) * NBLK;
+            const int by = blk / G::NB, bx = blk - by * G::NB;
+            const int o = bytab[qi * G::NB + by] + bxtab[qi * G::NB + bx];
+            off[i] = (e < QB * NBLK && o >= 0) ? o : -1;
+            v[i] = *(const float4*)(vol + max(o, 0));     // absent blocks read a valid dummy address
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * 256;
+            if (e >= QB * NBLK) continue;
+            const int qi = e / NBLK, blk = e - qi * NBLK;
+            const int by = blk / G::NB, bx = blk - by * G::NB;
+            const int xm = off[i] >= 0 ? (xmask[qi] >> (2 * bx)) : 0;
+            const int ym = ymask[qi] >> (2 * by);
+            float* t = tile + qi * G::STQ + (2 * by) * G::TW + 2 * bx;
+            t[0] = ((xm & 1) && (ym & 1)) ? v[i].x : 0.f;
+            t[1] = ((xm & 2) && (ym & 1)) ? v[i].y : 0.f;
+            t[G::TW] = ((xm & 1) && (ym & 2)) ? v[i].z : 0.f;
+            t[G::TW + 1] = ((xm & 2) && (ym & 2)) ? v[i].w : 0.f;
+        }
+    }
+    __syncthreads();
+    RC_STAMP(2);
+
+    constexpr int rd2 = G::RD * G::RD;
+    const int C = p.L * rd2;
+    if (p.mode == RAFTCORR_MODE_FORK) {
+        // out (B, N, C): lanes run along the channel dim
+        float* __restrict__ out = p.out + ((size_t)b * N + q0) * C + l * rd2;
+        constexpr int NOUT = (QB * rd2 + 255) / 256;
+        float o[NOUT];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int e = tid + i * 256;
+            const int qi = min(e / rd2, QB - 1), ch = e - (e / rd2) * rd2;
+            const int a = ch / G::RD, bb = ch - a * G::RD;
+            const float fx = sfx[qi], fy = sfy[qi];
+            const int par = spar[qi];
+            const float* tp = tile + qi * G::STQ + (bb + (par >> 1)) * G::TW + a + (par & 1);
+            o[i] = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
+                   tp[G::TW] * ((1.f - fx) * fy) + tp[G::TW + 1] * (fx * fy);
+        }
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int e = tid + i * 256;
+            const int qi = e / rd2, ch = e - qi * rd2;
+            if (e < QB * rd2 && q0 + qi < N) __builtin_nontemporal_store(o[i], &out[(size_t)qi * C + ch]);
+        }
+    } else {
+        // out (B, C, N): lanes run along the query dim
+        float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
+        const int qi = tid & (QB - 1);
+        const bool vq = q0 + qi < N;
+        const float fx = sfx[qi], fy = sfy[qi];
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
+        const float w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const int par = spar[qi];
+        const float* tq = tile + qi * G::STQ + (par >> 1) * G::TW + (par & 1);
+        constexpr int NOUT = (rd2 + 7) / 8;
+        float o[NOUT];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {          // all LDS reads of the thread in flight together
+            const int ch = min(tid / QB + i * 8, rd2 - 1);
+            const int a = ch / G::RD, bb = ch - a * G::RD;
+            const float* tp = tq + bb * G::TW + a;
+            o[i] = tp[0] * w00 + tp[1] * w01 + tp[G::TW] * w10 + tp[G::TW + 1] * w11;
+        }
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int ch = tid / QB + i * 8;
+            if (vq && ch < rd2) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
+        }
+    }
+    RC_STAMP(3);
+}
+
 template <int R, int KIND>
 __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem)
 {
@@ -290,12 +460,25 @@ __global__ __launch_bounds__(256)
 void corr_lookup_fwd_kernel(LookupArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    switch (p.lv.g[blockIdx.y].kind) {           // block-uniform
-    case 0: lookup_fwd_body<R, 0>(p, smem); break;
-    case 1: lookup_fwd_body<R, 1>(p, smem); break;
-    case 2: lookup_fwd_body<R, 2>(p, smem); break;
-    case 3: lookup_fwd_body<R, 3>(p, smem); break;
-    default: lookup_fwd_body<R, 4>(p, smem); break;
+    const int kind = p.lv.g[blockIdx.y].kind;    // block-uniform
+    if constexpr (R >= 0) {
+        if (threadIdx.x < QB) ((int*)(smem + QB * BlockGeom<R>::STQ + 2 * QB * BlockGeom<R>::NB))[4 * QB + threadIdx.x] = 0;  // spar
+        __syncthreads();
+        switch (kind) {
+        case 0: lookup_fwd_blocks<R, 0>(p, smem); return;
+        case 1: lookup_fwd_blocks<R, 1>(p, smem); return;
+        case 2: lookup_fwd_blocks<R, 2>(p, smem); return;
+        case 3: lookup_fwd_blocks<R, 3>(p, smem); return;
+        default: lookup_fwd_body<R, 4>(p, smem); return;
+        }
+    } else {
+        switch (kind) {
+        case 0: lookup_fwd_body<R, 0>(p, smem); break;
+        case 1: lookup_fwd_body<R, 1>(p, smem); break;
+        case 2: lookup_fwd_body<R, 2>(p, smem); break;
+        case 3: lookup_fwd_body<R, 3>(p, smem); break;
+        default: lookup_fwd_body<R, 4>(p, smem); break;
+        }
     }
 }
 
@@ -449,7 +632,13 @@ static size_t lookup_smem(int r, bool bwd)
 {
     const int T = 2 * r + 2, rd = 2 * r + 1;
     const int stride = bwd ? ((rd * rd) | 1) : ((T * T) | 1);
-    return sizeof(float) * ((size_t)QB * stride + 2 * QB + 2 * QB * T);
+    size_t fl = (size_t)QB * stride + 2 * QB + 2 * QB * T;
+    if (!bwd) {                                   // block-load path (compile-time radius)
+        const int NB = T / 2 + 1, TW = 2 * NB;
+        const size_t f4 = (size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 5 * QB;
+        if (f4 > fl) fl = f4;
+    }
+    return sizeof(float) * fl;
 }
 
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,

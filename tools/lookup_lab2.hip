@@ -20,7 +20,7 @@ int main()
 {
     const int H = 55, W = 128, N = H * W, L = 4, NC = 32, r = 4;
     LevelSet lv;
-    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.g[l] = LevelGeom{0, 0, 0, 4, 0}; }
+    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) { lv.ptr[l] = nullptr; lv.g[l] = LevelGeom{0, 0, 0, 0, 0, 4, 0}; }
     for (int l = 0; l < L; ++l) {
         lv.g[l] = level_geom(H, W, l);
         size_t n = (size_t)N * lv.g[l].slab;
