@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations' pieces (not the headline bench):
+alt (on-the-fly) fwd/bwd at KITTI 47x156, all-pairs fwd+bwd at FlyingThings 50x90 B=6."""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raft_amd import CorrBlock, AlternateCorrBlock
+
+dev = torch.device("cuda:0")
+
+def ev_time(fn, reps=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+def coords_for(B, H, W, sigma, g):
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    base = torch.stack([xx, yy], 0)[None].repeat(B, 1, 1, 1)
+    return (base + sigma * torch.randn(B, 2, H, W, generator=g)).to(dev)
+
+g = torch.Generator().manual_seed(0)
+res = {}
+# config 3: KITTI alt path
+B, D, H, W = 1, 256, 47, 156
+f1 = torch.randn(B, D, H, W, generator=g).to(dev); f2 = torch.randn(B, D, H, W, generator=g).to(dev)
+co = coords_for(B, H, W, 4.0, g)
+with torch.no_grad():
+    blk = AlternateCorrBlock(f1, f2, 4, 4)
+    res["kitti_alt_fwd_us"] = ev_time(lambda: blk(co))
+    cb = CorrBlock(f1, f2, 4, 4)
+    res["kitti_allpairs_lookup_us"] = ev_time(lambda: cb(co))
+    res["kitti_allpairs_build_us"] = ev_time(lambda: CorrBlock(f1, f2, 4, 4))
+f1g = f1.clone().requires_grad_(True); f2g = f2.clone().requires_grad_(True)
+gout = torch.randn(B, 324, H, W, generator=g).to(dev)
+def alt_fb():
+    f1g.grad = None; f2g.grad = None
+    AlternateCorrBlock(f1g, f2g, 4, 4)(co).backward(gout)
+res["kitti_alt_fwd_bwd_us"] = ev_time(alt_fb, reps=5, warm=2)
+# config 4: FlyingThings crops B=6, 12 lookups fwd + bwd
+B, D, H, W = 6, 256, 50, 90
+f1 = torch.randn(B, D, H, W, generator=g).to(dev).requires_grad_(True)
+f2 = torch.randn(B, D, H, W, generator=g).to(dev).requires_grad_(True)
+cos = [coords_for(B, H, W, 2.0 * (k + 1) ** 0.5, g) for k in range(12)]
+gouts = [torch.randn(B, 324, H, W, generator=g).to(dev) for _ in range(12)]
+def things_fwd():
+    with torch.no_grad():
+        cb = CorrBlock(f1, f2, 4, 4)
+        for c in cos: cb(c)
+def things_fb():
+    f1.grad = None; f2.grad = None
+    cb = CorrBlock(f1, f2, 4, 4)
+    loss = 0
+    for c, go in zip(cos, gouts): loss = loss + (cb(c) * go).sum()
+    loss.backward()
+res["things_b6_fwd_us"] = ev_time(things_fwd, reps=10)
+res["things_b6_fwd_bwd_us"] = ev_time(things_fb, reps=5, warm=2)
+print(json.dumps(res))
