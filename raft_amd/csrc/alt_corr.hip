@@ -314,29 +314,4 @@ int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, 
     return alt_bwd_common(a, s);
 }
 
-int launch_alt_lookup_fwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
-                          int r, const float* coords, float* out, hipStream_t s)
-{
-    int rc = alt_check(C, r, "alt_lookup_fwd");
-    if (rc) return rc;
-    AltArgs a = {};
-    a.f1 = f1; a.f2 = f2lv; a.coords = coords; a.out = out;
-    a.B = B; a.Nc = 1; a.P = H * W; a.C = C; a.L = L; a.r = r;
-    a.planar = 1; a.level_scale = 1; a.out_div = sqrtf((float)C);
-    return alt_fwd_common(a, s);
-}
-
-int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
-                          int r, const float* coords, const float* dout, float* df1,
-                          const LevelSet& df2lv, hipStream_t s)
-{
-    int rc = alt_check(C, r, "alt_lookup_bwd");
-    if (rc) return rc;
-    AltArgs a = {};
-    a.f1 = f1; a.f2 = f2lv; a.df2 = df2lv; a.coords = coords; a.dout = dout; a.df1 = df1;
-    a.B = B; a.Nc = 1; a.P = H * W; a.C = C; a.L = L; a.r = r;
-    a.planar = 1; a.level_scale = 1; a.out_div = sqrtf((float)C);
-    return alt_bwd_common(a, s);
-}
-
 }  // namespace raftcorr

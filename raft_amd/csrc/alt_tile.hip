@@ -1,0 +1,431 @@
+// On-the-fly correlation, all levels fused, as TILE GEMMS on the matrix cores.
+//
+// Replaces AlternateCorrBlock.__call__ (core/corr.py:75-92: per-level permute + alt_cuda_corr.forward
+// + stack + 1/sqrt(C)) and its backward (alt_cuda_corr/correlation_kernel.cu:123-256).
+//
+// Neighbouring queries look at overlapping windows: a 4x8 tile of queries whose flow is locally
+// smooth touches, at level l, a bounding box of only ~(8/2^l + 2r + 2) x (4/2^l + 2r + 2) targets,
+// while its 32 windows hold 32 x (2r+2)^2 taps.  So a workgroup
+//   1. finds the bounding box of its 32 windows (clipped to the level; any flow field is legal:
+//      a box larger than UC targets is walked in chunks of UC),
+//   2. computes the dense product  S[q][u] = <fmap1[:, q], fmap2_l[:, u]>  of its 32 queries with
+//      the UC box targets on MFMA (fp32 32x32x2, exact fp32 products/accumulation),
+//      operands staged channel-chunk by channel-chunk through LDS from the NHWC maps (a target's
+//      32-channel chunk is exactly one 128-byte line, so no fetched byte is wasted),
+//   3. lets every query pick its (2r+2)^2 taps out of S in LDS and blend them bilinearly.
+// fmap2 is read once per tile instead of once per query, and nothing is reduced across lanes.
+//
+// Backward runs the same tiling with the tap-gradient matrix G[q][u] (the 2x2 box filter of
+// d(out), scattered to box positions) as the shared operand of two GEMMs per channel chunk:
+//   d(fmap1)[c][q] = sum_u fmap2[c][u] G[q][u]      d(fmap2)[c][u] = sum_q fmap1[c][q] G[q][u]
+// d(fmap2) of a tile is added to memory with one float atomic per (channel, box target) instead
+// of one per (channel, query, tap) as in the reference (:239-250), 128 contiguous bytes per
+// wave-instruction; d(fmap1) is reduced over the four waves in LDS first.
+//
+// Workgroups are numbered so that each XCD (workgroup id mod 8) owns a band of tile rows: the
+// band's part of fmap2 stays in that XCD's L2 while neighbouring tiles re-read it.
+#include "common.h"
+#include <limits.h>
+
+namespace raftcorr {
+
+namespace {
+
+constexpr int TQW = 8, TQH = 4, TQ = TQW * TQH;   // query tile
+constexpr int UC = 256;                           // box targets per chunk (4 waves x 2 MFMA column tiles)
+constexpr int KC = 32;                            // channels per staged chunk
+constexpr int LDU = UC + 1;                       // odd strides: row- and column-indexed reads conflict-free
+constexpr int LDQ = TQ + 1;
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct AltTileArgs {
+    const float* f1;            // (B, H, W, C)
+    LevelSet f2;                // level l: (B, H_l, W_l, C)
+    LevelSet df2;               // bwd: accumulated with atomics
+    const float* coords;        // (B, 2, H, W)
+    const float* dout;          // bwd: (B, L*rd2, H, W)
+    float* out;                 // fwd: (B, L*rd2, H, W)
+    float* df1;                 // bwd: (B, H, W, C), accumulated with atomics (zeroed by the launcher)
+    int B, C, H, W, L, r;
+    int band;                   // tiles per XCD band
+    int vec;                    // C % 4 == 0 and 16-byte aligned maps: float4 staging
+    float out_div;
+};
+
+struct Tile {
+    int b, l, ty0, tx0, Hl, Wl, HWl;
+    bool live;
+    int xmin, ymin, bw, U;
+};
+
+struct TileShared {
+    int wx0[TQ], wy0[TQ];       // window origin (x0 - r, y0 - r) per query
+    float fx[TQ], fy[TQ];
+    int box[4];
+    int toff[UC];               // offset (pixels) of the chunk's box targets in the level, -1 beyond the box
+};
+
+// queries' window origins + the bounding box of their in-level parts
+__device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh)
+{
+    Tile t;
+    const int tiles_x = (p.W + TQW - 1) / TQW, tiles = tiles_x * ((p.H + TQH - 1) / TQH);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int j = idx % p.band, bl = idx / p.band;
+    const int tile = xcd * p.band + j;
+    t.l = bl % p.L; t.b = bl / p.L;
+    t.live = tile < tiles;
+    if (!t.live) return t;                                       // whole workgroup
+    t.ty0 = (tile / tiles_x) * TQH;
+    t.tx0 = (tile % tiles_x) * TQW;
+    t.Hl = p.f2.g[t.l].h; t.Wl = p.f2.g[t.l].w; t.HWl = t.Hl * t.Wl;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int qi = tid & 31, gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
+        const bool valid = tid < 32 && gy < p.H && gx < p.W;
+        const int T = 2 * p.r + 2;
+        int wx0 = -(1 << 24), wy0 = -(1 << 24);
+        float fx = 0.f, fy = 0.f;
+        if (valid) {
+            const size_t P = (size_t)p.H * p.W;
+            const float* c = p.coords + (size_t)t.b * 2 * P + (size_t)gy * p.W + gx;
+            const float s = 1.0f / (float)(1 << t.l);           // coords / 2**l, corr.py:82
+            int x0, y0;
+            split_coord(c[0] * s, x0, fx);
+            split_coord(c[P] * s, y0, fy);
+            wx0 = x0 - p.r; wy0 = y0 - p.r;
+        }
+        const int qx0 = max(wx0, 0), qx1 = min(wx0 + T - 1, t.Wl - 1);
+        const int qy0 = max(wy0, 0), qy1 = min(wy0 + T - 1, t.Hl - 1);
+        const bool has = valid && qx0 <= qx1 && qy0 <= qy1;
+        int mnx = has ? qx0 : INT_MAX, mxx = has ? qx1 : INT_MIN;
+        int mny = has ? qy0 : INT_MAX, mxy = has ? qy1 : INT_MIN;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, m)); mxx = max(mxx, __shfl_xor(mxx, m));
+            mny = min(mny, __shfl_xor(mny, m)); mxy = max(mxy, __shfl_xor(mxy, m));
+        }
+        if (tid < 32) { sh.wx0[qi] = wx0; sh.wy0[qi] = wy0; sh.fx[qi] = fx; sh.fy[qi] = fy; }
+        if (tid == 0) { sh.box[0] = mnx; sh.box[1] = mxx; sh.box[2] = mny; sh.box[3] = mxy; }
+    }
+    __syncthreads();
+    const int mnx = sh.box[0], mxx = sh.box[1], mny = sh.box[2], mxy = sh.box[3];
+    if (mnx > mxx || mny > mxy) { t.xmin = 0; t.ymin = 0; t.bw = 1; t.U = 0; }
+    else { t.xmin = mnx; t.ymin = mny; t.bw = mxx - mnx + 1; t.U = t.bw * (mxy - mny + 1); }
+    return t;
+}
+
+// offset of box target u inside a level plane, or -1 beyond the box
+__device__ __forceinline__ int box_offset(const Tile& t, int u)
+{
+    if (u >= t.U) return -1;
+    const int uy = u / t.bw, ux = u - uy * t.bw;
+    return (t.ymin + uy) * t.Wl + t.xmin + ux;
+}
+
+// chunk-relative box index of level cell (y, x), or -1 when outside the box / the chunk
+__device__ __forceinline__ int box_index(const Tile& t, int bh, int y, int x, int ubase)
+{
+    const int ry = y - t.ymin, rx = x - t.xmin;
+    const int u = ry * t.bw + rx - ubase;
+    const bool ok = (unsigned)rx < (unsigned)t.bw && (unsigned)ry < (unsigned)bh && (unsigned)u < (unsigned)UC;
+    return ok ? u : -1;
+}
+
+struct Stage {                   // one channel chunk of both operands, in flight in registers
+    float4 rb[UC / 32];          // fmap2: 8 box targets x 4 channels
+    float4 ra;                   // fmap1: 1 query x 4 channels
+};
+
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ base, int off, int c, int C, int vec)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (off < 0) return v;
+    const float* __restrict__ src = base + (size_t)off * C + c;
+    if (vec) { if (c < C) v = *(const float4*)src; }
+    else {
+        if (c < C) v.x = src[0];
+        if (c + 1 < C) v.y = src[1];
+        if (c + 2 < C) v.z = src[2];
+        if (c + 3 < C) v.w = src[3];
+    }
+    return v;
+}
+
+// thread (kq = tid & 7, ut = tid >> 3): channels c0 + 4kq .. +3 of box targets ut + 32 i and of
+// query ut -- eight lanes read one 128-byte line
+__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ f1b, const float* __restrict__ f2b,
+                                           int c0, int C, int vec, const int* toff, int q_off_stage)
+{
+    const int tid = threadIdx.x, c = c0 + 4 * (tid & 7), ut = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < UC / 32; ++i) st.rb[i] = load_quad(f2b, toff[ut + 32 * i], c, C, vec);
+    st.ra = load_quad(f1b, q_off_stage, c, C, vec);
+}
+
+// transposed into [channel][target] / [channel][query]; bank = (4kq + j + ut) mod 32: conflict-free
+__device__ __forceinline__ void stage_store(const Stage& st, float* F2s, float* F1s)
+{
+    const int tid = threadIdx.x, k = 4 * (tid & 7), ut = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < UC / 32; ++i) {
+        float* d = F2s + k * LDU + ut + 32 * i;
+        d[0] = st.rb[i].x; d[LDU] = st.rb[i].y; d[2 * LDU] = st.rb[i].z; d[3 * LDU] = st.rb[i].w;
+    }
+    float* d = F1s + k * LDQ + ut;
+    d[0] = st.ra.x; d[LDQ] = st.ra.y; d[2 * LDQ] = st.ra.z; d[3 * LDQ] = st.ra.w;
+}
+
+__device__ __forceinline__ int query_offset(const AltTileArgs& p, const Tile& t, int qi)
+{
+    const int gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
+    return (gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  grid: 8 XCD bands x (tiles per band x L x B), block 256.
+// NOUT = ceil(32 * rd2 / 256) outputs per thread.
+template <int NOUT>
+__global__ __launch_bounds__(256)
+void alt_tile_fwd_kernel(AltTileArgs p)
+{
+    __shared__ float F2s[KC * LDU];          // staged fmap2 chunk [k][u]; later S[q][u]
+    __shared__ float F1s[KC * LDQ];          // staged fmap1 chunk [k][q]
+    __shared__ TileShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int r = p.r, rd = 2 * r + 1, rd2 = rd * rd;
+    const Tile t = tile_setup(p, sh);
+    if (!t.live) return;
+    const int bh = t.U / t.bw;
+    const size_t P = (size_t)p.H * p.W;
+    const float* __restrict__ f1b = p.f1 + (size_t)t.b * P * p.C;
+    const float* __restrict__ f2b = p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+    const int q_off = query_offset(p, t, tid & 31);          // the query this thread writes outputs of
+    const int q_stage = query_offset(p, t, tid >> 3);        // the query this thread stages
+    float o[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) o[i] = 0.f;
+
+    const int nk = (p.C + KC - 1) / KC;
+    for (int ubase = 0; ubase < t.U; ubase += UC) {
+        __syncthreads();
+        sh.toff[tid] = box_offset(t, ubase + tid);
+        __syncthreads();
+        const bool live0 = ubase + wave * 64 < t.U, live1 = ubase + wave * 64 + 32 < t.U;   // wave-uniform
+        v16f acc0 = {0}, acc1 = {0};
+        Stage st;
+        stage_load(st, f1b, f2b, 0, p.C, p.vec, sh.toff, q_stage);
+        for (int kc = 0; kc < nk; ++kc) {
+            __syncthreads();
+            stage_store(st, F2s, F1s);
+            __syncthreads();
+            if (kc + 1 < nk) stage_load(st, f1b, f2b, (kc + 1) * KC, p.C, p.vec, sh.toff, q_stage);
+            if (live1) {
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a = F1s[(2 * s + kh) * LDQ + l31];
+                    const float b0 = F2s[(2 * s + kh) * LDU + wave * 64 + l31];
+                    const float b1 = F2s[(2 * s + kh) * LDU + wave * 64 + 32 + l31];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                }
+            } else if (live0) {
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a = F1s[(2 * s + kh) * LDQ + l31];
+                    const float b0 = F2s[(2 * s + kh) * LDU + wave * 64 + l31];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        float* S = F2s;                                  // S[q][u], stride LDU
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+            S[row * LDU + wave * 64 + l31] = acc0[i];
+            S[row * LDU + wave * 64 + 32 + l31] = acc1[i];
+        }
+        __syncthreads();
+        const int qi = tid & 31;
+        const int wx = sh.wx0[qi], wy = sh.wy0[qi];
+        const float fx = sh.fx[qi], fy = sh.fy[qi];
+        const float* Sq = S + qi * LDU;
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int ch = (tid >> 5) + 8 * i;
+            if (ch < rd2) {
+                const int ai = ch / rd, bi = ch - ai * rd;           // ai <-> x offset (slow), bi <-> y offset
+                const int x = wx + ai, y = wy + bi;
+                const int u00 = box_index(t, bh, y, x, ubase), u01 = box_index(t, bh, y, x + 1, ubase);
+                const int u10 = box_index(t, bh, y + 1, x, ubase), u11 = box_index(t, bh, y + 1, x + 1, ubase);
+                const float v00 = u00 >= 0 ? Sq[u00] : 0.f, v01 = u01 >= 0 ? Sq[u01] : 0.f;
+                const float v10 = u10 >= 0 ? Sq[u10] : 0.f, v11 = u11 >= 0 ? Sq[u11] : 0.f;
+                o[i] += v00 * ((1.f - fx) * (1.f - fy)) + v01 * (fx * (1.f - fy)) +
+                        v10 * ((1.f - fx) * fy) + v11 * (fx * fy);
+            }
+        }
+    }
+    if (q_off >= 0) {
+        float* __restrict__ out = p.out + ((size_t)t.b * p.L + t.l) * rd2 * P + q_off;
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int ch = (tid >> 5) + 8 * i;
+            if (ch < rd2) out[(size_t)ch * P] = o[i] / p.out_div;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  Same grid.
+__global__ __launch_bounds__(256)
+void alt_tile_bwd_kernel(AltTileArgs p)
+{
+    __shared__ float F2s[KC * LDU];          // staged fmap2 chunk [c][u]; before the chunk loop: d(out) tile [ch][q]
+    __shared__ float F1s[KC * LDQ];          // staged fmap1 chunk [c][q]
+    __shared__ float G[TQ * LDU];            // tap gradients [q][u]
+    __shared__ float red[TQ * LDQ];          // d(fmap1) chunk [q][c], reduced over the waves
+    __shared__ TileShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int r = p.r, T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
+    const Tile t = tile_setup(p, sh);
+    if (!t.live) return;
+    const int bh = t.U / t.bw;
+    const size_t P = (size_t)p.H * p.W;
+    const float* __restrict__ f1b = p.f1 + (size_t)t.b * P * p.C;
+    const float* __restrict__ f2b = p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+    float* __restrict__ df1b = p.df1 + (size_t)t.b * P * p.C;
+    float* __restrict__ df2b = p.df2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+    const int q_off = query_offset(p, t, tid & 31);
+    const int q_stage = query_offset(p, t, tid >> 3);
+    const float* __restrict__ dout = p.dout + ((size_t)t.b * p.L + t.l) * rd2 * P;
+    const float inv_div = 1.0f / p.out_div;
+    const int nk = (p.C + KC - 1) / KC;
+
+    for (int ubase = 0; ubase < t.U; ubase += UC) {
+        __syncthreads();
+        float* Ds = F2s;                                            // [ch][q], stride 32
+        for (int e = tid; e < rd2 * TQ; e += 256)
+            Ds[e] = q_off >= 0 ? dout[(size_t)(e >> 5) * P + q_off] : 0.f;   // (e & 31) == (tid & 31)
+        for (int e = tid; e < TQ * LDU; e += 256) G[e] = 0.f;
+        sh.toff[tid] = box_offset(t, ubase + tid);
+        __syncthreads();
+        for (int e = tid; e < TT * TQ; e += 256) {
+            const int qi = e & 31, tp = e >> 5;
+            const int ty = tp / T, tx = tp - ty * T;
+            const int u = box_index(t, bh, sh.wy0[qi] + ty, sh.wx0[qi] + tx, ubase);
+            if (u >= 0) {
+                const float fx = sh.fx[qi], fy = sh.fy[qi];
+                float g = 0.f;
+                if (tx < rd && ty < rd) g += Ds[(tx * rd + ty) * TQ + qi] * ((1.f - fx) * (1.f - fy));
+                if (tx > 0 && ty < rd)  g += Ds[((tx - 1) * rd + ty) * TQ + qi] * (fx * (1.f - fy));
+                if (tx < rd && ty > 0)  g += Ds[(tx * rd + ty - 1) * TQ + qi] * ((1.f - fx) * fy);
+                if (tx > 0 && ty > 0)   g += Ds[((tx - 1) * rd + ty - 1) * TQ + qi] * (fx * fy);
+                G[qi * LDU + u] = g * inv_div;
+            }
+        }
+        const int ulive = min(t.U - ubase - wave * 64, 64);        // box targets of this wave, wave-uniform
+        Stage st;
+        stage_load(st, f1b, f2b, 0, p.C, p.vec, sh.toff, q_stage);
+        for (int kc = 0; kc < nk; ++kc) {
+            const int c0 = kc * KC;
+            __syncthreads();
+            stage_store(st, F2s, F1s);
+#pragma unroll
+            for (int i = 0; i < TQ * KC / 256; ++i) red[((tid >> 5) + 8 * i) * LDQ + (tid & 31)] = 0.f;
+            __syncthreads();
+            if (kc + 1 < nk) stage_load(st, f1b, f2b, c0 + KC, p.C, p.vec, sh.toff, q_stage);
+            if (ulive > 0) {
+                // d(fmap1)[q][c] += sum over this wave's box targets   (rows q, lanes c)
+                v16f acc = {0};
+                const int ns = min((ulive + 1) >> 1, 32);
+                for (int s = 0; s < ns; ++s) {
+                    const int u = wave * 64 + 2 * s + kh;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(G[l31 * LDU + u], F2s[l31 * LDU + u], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    atomicAdd(&red[row * LDQ + l31], acc[i]);
+                }
+                // d(fmap2)[u][c] for this wave's box targets, all 32 queries   (rows u, lanes c)
+                v16f acc0 = {0}, acc1 = {0};
+#pragma unroll
+                for (int s = 0; s < TQ / 2; ++s) {
+                    const float b = F1s[l31 * LDQ + 2 * s + kh];
+                    const float a0 = G[(2 * s + kh) * LDU + wave * 64 + l31];
+                    const float a1 = G[(2 * s + kh) * LDU + wave * 64 + 32 + l31];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                }
+                if (c0 + l31 < p.C) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                        const int o0 = sh.toff[wave * 64 + row], o1 = sh.toff[wave * 64 + 32 + row];
+                        if (o0 >= 0) atomicAdd(df2b + (size_t)o0 * p.C + c0 + l31, acc0[i]);
+                        if (o1 >= 0) atomicAdd(df2b + (size_t)o1 * p.C + c0 + l31, acc1[i]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (q_stage >= 0) {                                   // thread (query tid >> 3, channel quad tid & 7)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * (tid & 7) + j;
+                    if (c0 + c < p.C) atomicAdd(df1b + (size_t)q_stage * p.C + c0 + c, red[(tid >> 3) * LDQ + c]);
+                }
+            }
+        }
+    }
+}
+
+int tile_prepare(AltTileArgs& a, const char* who)
+{
+    if (a.r > 7) return fail(RAFTCORR_EUNSUPPORTED, "%s: radius %d > 7", who, a.r);
+    const int tiles = ((a.W + TQW - 1) / TQW) * ((a.H + TQH - 1) / TQH);
+    a.band = (tiles + 7) / 8;
+    bool aligned = ((uintptr_t)a.f1 & 15) == 0;
+    for (int l = 0; l < a.L; ++l) aligned = aligned && ((uintptr_t)a.f2.ptr[l] & 15) == 0;
+    a.vec = (a.C % 4 == 0) && aligned;
+    a.out_div = sqrtf((float)a.C);
+    return RAFTCORR_OK;
+}
+
+dim3 tile_grid(const AltTileArgs& a) { return dim3(8u * a.band * a.L * a.B); }
+
+}  // namespace
+
+int launch_alt_lookup_fwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
+                          int r, const float* coords, float* out, hipStream_t s)
+{
+    AltTileArgs a = {};
+    a.f1 = f1; a.f2 = f2lv; a.coords = coords; a.out = out;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
+    int rc = tile_prepare(a, "alt_lookup_fwd");
+    if (rc) return rc;
+    const int rd = 2 * r + 1;
+    if (TQ * rd * rd <= 256 * 11)
+        hipLaunchKernelGGL(alt_tile_fwd_kernel<11>, tile_grid(a), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(alt_tile_fwd_kernel<29>, tile_grid(a), dim3(256), 0, s, a);
+    return check_launch("alt_tile_fwd_kernel");
+}
+
+int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
+                          int r, const float* coords, const float* dout, float* df1,
+                          const LevelSet& df2lv, hipStream_t s)
+{
+    AltTileArgs a = {};
+    a.f1 = f1; a.f2 = f2lv; a.df2 = df2lv; a.coords = coords; a.dout = dout; a.df1 = df1;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
+    int rc = tile_prepare(a, "alt_lookup_bwd");
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(df1, 0, sizeof(float) * (size_t)B * C * H * W, s);
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_lookup_bwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(alt_tile_bwd_kernel, tile_grid(a), dim3(256), 0, s, a);
+    return check_launch("alt_tile_bwd_kernel");
+}
+
+}  // namespace raftcorr

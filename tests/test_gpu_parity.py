@@ -255,6 +255,48 @@ def test_alternate_corr_block_matches_canonical_reference(name, dev):
         assert rel_err(f2.grad.cpu().numpy(), g["dfmap2"]) <= GTOL
 
 
+@pytest.mark.parametrize("case", [(1, 40, 13, 19, 3, 3, "wild"), (2, 32, 12, 21, 2, 5, "smooth"),
+                                  (1, 64, 24, 40, 4, 4, "wild"), (1, 7, 9, 10, 2, 1, "outside")])
+def test_alternate_corr_block_edge_cases(case, dev):
+    """Tile kernels of the on-the-fly path against the oracle's canonical CorrBlock (fwd + bwd):
+    channel counts that are not a multiple of the staged chunk, ragged query tiles, incoherent
+    flow (bounding boxes of many chunks), windows partly / entirely outside the map, radius > 4."""
+    from raft_amd import AlternateCorrBlock
+    from oracle import corr_oracle as O
+    B, C, H, W, L, r, kind = case
+    rs = np.random.RandomState(sum(case[:6]))
+    f1n = rs.randn(B, C, H, W).astype(np.float32)
+    f2n = rs.randn(B, C, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].astype(np.float32)
+    if kind == "wild":
+        con = (rs.rand(B, 2, H, W) * [[[W + 12]], [[H + 12]]] - 6).astype(np.float32)
+        con[0, :, 0, 0] = [1e9, -3.0]
+        con[0, :, 1, 1] = [np.inf, 2.0]
+    elif kind == "smooth":
+        con = base + 1.5 * rs.randn(B, 2, 1, 1).astype(np.float32) + 0.3 * rs.randn(B, 2, H, W).astype(np.float32)
+    else:
+        con = base + 1000.0
+        con[0, :, 2, 3] = [4.25, 3.5]
+    gn = rs.randn(B, L * (2 * r + 1) ** 2, H, W).astype(np.float32)
+
+    def run(make, device, co):
+        f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+        out = make(f1, f2)(torch.from_numpy(co).to(device))
+        out.backward(torch.from_numpy(gn).to(device))
+        return out.detach().cpu().numpy(), f1.grad.cpu().numpy(), f2.grad.cpu().numpy()
+
+    # non-finite / absurd coordinates are defined here as "far outside" (all taps zero); the
+    # oracle gets the same thing spelled as a finite far-away coordinate
+    con_ref = np.where(np.isfinite(con) & (np.abs(con) < 1e6), con, -1e5).astype(np.float32)
+    o, g1, g2 = run(lambda a, b: AlternateCorrBlock(a, b, num_levels=L, radius=r), dev, con)
+    ro, r1, r2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu", con_ref)
+    assert o.shape == ro.shape
+    assert rel_err(o, ro) <= TOL
+    assert rel_err(g1, r1) <= GTOL and rel_err(g2, r2) <= GTOL
+
+
 def test_alt_equals_all_pairs_at_kitti_shape(dev):
     """Config 3 shape (47x156, D=256): both of our paths agree with each other."""
     from raft_amd import AlternateCorrBlock, CorrBlock

@@ -23,6 +23,12 @@ def coords_for(B, H, W, sigma, g):
     base = torch.stack([xx, yy], 0)[None].repeat(B, 1, 1, 1)
     return (base + sigma * torch.randn(B, 2, H, W, generator=g)).to(dev)
 
+def smooth_coords_for(B, H, W, amp, g):
+    """piecewise-smooth flow, the kind RAFT iterates on: a coarse random field upsampled + 0.25 px noise"""
+    coarse = amp * torch.randn(B, 2, 2, 3, generator=g)
+    flow = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=True)
+    return coords_for(B, H, W, 0.25, g) + flow.to(dev)
+
 g = torch.Generator().manual_seed(0)
 res = {}
 # config 3: KITTI alt path
@@ -41,6 +47,15 @@ def alt_fb():
     f1g.grad = None; f2g.grad = None
     AlternateCorrBlock(f1g, f2g, 4, 4)(co).backward(gout)
 res["kitti_alt_fwd_bwd_us"] = ev_time(alt_fb, reps=5, warm=2)
+co_s = smooth_coords_for(B, H, W, 8.0, g)
+with torch.no_grad():
+    res["kitti_alt_fwd_smooth_us"] = ev_time(lambda: blk(co_s))
+    co_i = coords_for(B, H, W, 0.0, g)
+    res["kitti_alt_fwd_identity_us"] = ev_time(lambda: blk(co_i))
+def alt_fb_s():
+    f1g.grad = None; f2g.grad = None
+    AlternateCorrBlock(f1g, f2g, 4, 4)(co_s).backward(gout)
+res["kitti_alt_fwd_bwd_smooth_us"] = ev_time(alt_fb_s, reps=5, warm=2)
 # config 4: FlyingThings crops B=6, 12 lookups fwd + bwd
 B, D, H, W = 6, 256, 50, 90
 f1 = torch.randn(B, D, H, W, generator=g).to(dev).requires_grad_(True)
