@@ -1,7 +1,12 @@
-// On-the-fly correlation, all levels fused, as TILE GEMMS on the matrix cores.
+// On-the-fly ("alternate") correlation -- the memory-lean path that never materialises the
+// all-pairs volume -- as TILE GEMMS on the matrix cores.  Forward and backward; one level with
+// the reference's pybind calling convention (alt_cuda_corr/correlation_kernel.cu:19-119 forward,
+// :123-256 backward, launched from :260-324) and all levels fused (AlternateCorrBlock.__call__,
+// core/corr.py:75-92: per-level permute + kernel call + stack + 1/sqrt(C)).
 //
-// Replaces AlternateCorrBlock.__call__ (core/corr.py:75-92: per-level permute + alt_cuda_corr.forward
-// + stack + 1/sqrt(C)) and its backward (alt_cuda_corr/correlation_kernel.cu:123-256).
+// The reference kernel runs 32-thread blocks (<1 wave per CU on this part), re-reads fmap2
+// through a 32-channel shared-memory chunk with two barriers per tap and does 3200 global
+// read-modify-writes per pixel.  Here:
 //
 // Neighbouring queries look at overlapping windows: a 4x8 tile of queries whose flow is locally
 // smooth touches, at level l, a bounding box of only ~(8/2^l + 2r + 2) x (4/2^l + 2r + 2) targets,
@@ -26,6 +31,7 @@
 // band's part of fmap2 stays in that XCD's L2 while neighbouring tiles re-read it.
 #include "common.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace raftcorr {
 
@@ -43,18 +49,20 @@ struct AltTileArgs {
     const float* f1;            // (B, H, W, C)
     LevelSet f2;                // level l: (B, H_l, W_l, C)
     LevelSet df2;               // bwd: accumulated with atomics
-    const float* coords;        // (B, 2, H, W)
-    const float* dout;          // bwd: (B, L*rd2, H, W)
-    float* out;                 // fwd: (B, L*rd2, H, W)
+    const float* coords;        // planar: (B, 2, H, W);  else (B, Nc, H, W, 2)
+    const float* dout;          // bwd: (B*Nc, L*rd2, H, W)
+    float* out;                 // fwd: (B*Nc, L*rd2, H, W)
     float* df1;                 // bwd: (B, H, W, C), accumulated with atomics (zeroed by the launcher)
-    int B, C, H, W, L, r;
+    int B, Nc, C, H, W, L, r;   // Nc coordinate sets per image (the reference's N, correlation_kernel.cu:264)
+    int planar;                 // coords layout, see above (planar needs Nc == 1)
+    int level_scale;            // 1: level l samples at coords / 2**l (corr.py:82); 0: coords as given
     int band;                   // tiles per XCD band
-    int vec;                    // C % 4 == 0 and 16-byte aligned maps: float4 staging
+    int vec;                    // C % 4 == 0 and 16-byte aligned maps: float4 staging (host-side dispatch)
     float out_div;
 };
 
 struct Tile {
-    int b, l, ty0, tx0, Hl, Wl, HWl;
+    int b, n, l, ty0, tx0, Hl, Wl, HWl;   // n: coordinate set
     bool live;
     int xmin, ymin, bw, U;
 };
@@ -74,7 +82,9 @@ __device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int j = idx % p.band, bl = idx / p.band;
     const int tile = xcd * p.band + j;
-    t.l = bl % p.L; t.b = bl / p.L;
+    t.l = bl % p.L;
+    const int bn = bl / p.L;
+    t.b = bn / p.Nc; t.n = bn - t.b * p.Nc;
     t.live = tile < tiles;
     if (!t.live) return t;                                       // whole workgroup
     t.ty0 = (tile / tiles_x) * TQH;
@@ -88,12 +98,14 @@ __device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh)
         int wx0 = -(1 << 24), wy0 = -(1 << 24);
         float fx = 0.f, fy = 0.f;
         if (valid) {
-            const size_t P = (size_t)p.H * p.W;
-            const float* c = p.coords + (size_t)t.b * 2 * P + (size_t)gy * p.W + gx;
-            const float s = 1.0f / (float)(1 << t.l);           // coords / 2**l, corr.py:82
+            const size_t P = (size_t)p.H * p.W, q = (size_t)gy * p.W + gx;
+            float x, y;
+            if (p.planar) { const float* c = p.coords + (size_t)t.b * 2 * P + q; x = c[0]; y = c[P]; }
+            else { const float* c = p.coords + (((size_t)t.b * p.Nc + t.n) * P + q) * 2; x = c[0]; y = c[1]; }
+            const float s = p.level_scale ? 1.0f / (float)(1 << t.l) : 1.0f;
             int x0, y0;
-            split_coord(c[0] * s, x0, fx);
-            split_coord(c[P] * s, y0, fy);
+            split_coord(x * s, x0, fx);
+            split_coord(y * s, y0, fy);
             wx0 = x0 - p.r; wy0 = y0 - p.r;
         }
         const int qx0 = max(wx0, 0), qx1 = min(wx0 + T - 1, t.Wl - 1);
@@ -138,30 +150,39 @@ struct Stage {                   // one channel chunk of both operands, in fligh
     float4 ra;                   // fmap1: 1 query x 4 channels
 };
 
-__device__ __forceinline__ float4 load_quad(const float* __restrict__ base, int off, int c, int C, int vec)
+// Branch-free by construction (all loads of a stage must be in flight together): buffer loads,
+// where an out-of-range offset returns zero instead of faulting, so "no such target / channel"
+// is just the offset OOB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;        // maps are < 2 GiB per image (checked on the host)
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_quad(__amdgpu_buffer_rsrc_t rsrc, int off, int c, int C)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (off < 0) return v;
-    const float* __restrict__ src = base + (size_t)off * C + c;
-    if (vec) { if (c < C) v = *(const float4*)src; }
-    else {
-        if (c < C) v.x = src[0];
-        if (c + 1 < C) v.y = src[1];
-        if (c + 2 < C) v.z = src[2];
-        if (c + 3 < C) v.w = src[3];
+    const unsigned base = ((unsigned)off * (unsigned)C + (unsigned)c) * 4u;
+    float4 v;
+    if (VEC) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off < 0 || c >= C) ? OOB : base, 0, 0);
+        v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    } else {
+        v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off < 0 || c >= C) ? OOB : base, 0, 0));
+        v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off < 0 || c + 1 >= C) ? OOB : base + 4, 0, 0));
+        v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off < 0 || c + 2 >= C) ? OOB : base + 8, 0, 0));
+        v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off < 0 || c + 3 >= C) ? OOB : base + 12, 0, 0));
     }
     return v;
 }
 
 // thread (kq = tid & 7, ut = tid >> 3): channels c0 + 4kq .. +3 of box targets ut + 32 i and of
 // query ut -- eight lanes read one 128-byte line
-__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ f1b, const float* __restrict__ f2b,
-                                           int c0, int C, int vec, const int* toff, int q_off_stage)
+template <bool VEC>
+__device__ __forceinline__ void stage_load(Stage& st, __amdgpu_buffer_rsrc_t f1b, __amdgpu_buffer_rsrc_t f2b,
+                                           int c0, int C, const int* toff, int q_off_stage)
 {
     const int tid = threadIdx.x, c = c0 + 4 * (tid & 7), ut = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < UC / 32; ++i) st.rb[i] = load_quad(f2b, toff[ut + 32 * i], c, C, vec);
-    st.ra = load_quad(f1b, q_off_stage, c, C, vec);
+    for (int i = 0; i < UC / 32; ++i) st.rb[i] = load_quad<VEC>(f2b, toff[ut + 32 * i], c, C);
+    st.ra = load_quad<VEC>(f1b, q_off_stage, c, C);
 }
 
 // transposed into [channel][target] / [channel][query]; bank = (4kq + j + ut) mod 32: conflict-free
@@ -186,8 +207,8 @@ __device__ __forceinline__ int query_offset(const AltTileArgs& p, const Tile& t,
 // ---------------------------------------------------------------------------------------------
 // forward.  grid: 8 XCD bands x (tiles per band x L x B), block 256.
 // NOUT = ceil(32 * rd2 / 256) outputs per thread.
-template <int NOUT>
-__global__ __launch_bounds__(256)
+template <int NOUT, bool VEC>
+__global__ __launch_bounds__(256, NOUT <= 11 ? 3 : 2)
 void alt_tile_fwd_kernel(AltTileArgs p)
 {
     __shared__ float F2s[KC * LDU];          // staged fmap2 chunk [k][u]; later S[q][u]
@@ -199,8 +220,10 @@ void alt_tile_fwd_kernel(AltTileArgs p)
     if (!t.live) return;
     const int bh = t.U / t.bw;
     const size_t P = (size_t)p.H * p.W;
-    const float* __restrict__ f1b = p.f1 + (size_t)t.b * P * p.C;
-    const float* __restrict__ f2b = p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+    const __amdgpu_buffer_rsrc_t f1b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.f1) + (size_t)t.b * P * p.C, 0, (int)(P * p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t f2b = __builtin_amdgcn_make_buffer_rsrc(
+        p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C, 0, t.HWl * p.C * 4, 0x00020000);
     const int q_off = query_offset(p, t, tid & 31);          // the query this thread writes outputs of
     const int q_stage = query_offset(p, t, tid >> 3);        // the query this thread stages
     float o[NOUT];
@@ -215,12 +238,12 @@ void alt_tile_fwd_kernel(AltTileArgs p)
         const bool live0 = ubase + wave * 64 < t.U, live1 = ubase + wave * 64 + 32 < t.U;   // wave-uniform
         v16f acc0 = {0}, acc1 = {0};
         Stage st;
-        stage_load(st, f1b, f2b, 0, p.C, p.vec, sh.toff, q_stage);
+        stage_load<VEC>(st, f1b, f2b, 0, p.C, sh.toff, q_stage);
         for (int kc = 0; kc < nk; ++kc) {
             __syncthreads();
             stage_store(st, F2s, F1s);
             __syncthreads();
-            if (kc + 1 < nk) stage_load(st, f1b, f2b, (kc + 1) * KC, p.C, p.vec, sh.toff, q_stage);
+            if (kc + 1 < nk) stage_load<VEC>(st, f1b, f2b, (kc + 1) * KC, p.C, sh.toff, q_stage);
             if (live1) {
 #pragma unroll
                 for (int s = 0; s < KC / 2; ++s) {
@@ -268,7 +291,7 @@ void alt_tile_fwd_kernel(AltTileArgs p)
         }
     }
     if (q_off >= 0) {
-        float* __restrict__ out = p.out + ((size_t)t.b * p.L + t.l) * rd2 * P + q_off;
+        float* __restrict__ out = p.out + (((size_t)t.b * p.Nc + t.n) * p.L + t.l) * rd2 * P + q_off;
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
             const int ch = (tid >> 5) + 8 * i;
@@ -279,6 +302,7 @@ void alt_tile_fwd_kernel(AltTileArgs p)
 
 // ---------------------------------------------------------------------------------------------
 // backward.  Same grid.
+template <bool VEC>
 __global__ __launch_bounds__(256)
 void alt_tile_bwd_kernel(AltTileArgs p)
 {
@@ -293,13 +317,15 @@ void alt_tile_bwd_kernel(AltTileArgs p)
     if (!t.live) return;
     const int bh = t.U / t.bw;
     const size_t P = (size_t)p.H * p.W;
-    const float* __restrict__ f1b = p.f1 + (size_t)t.b * P * p.C;
-    const float* __restrict__ f2b = p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+    const __amdgpu_buffer_rsrc_t f1b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.f1) + (size_t)t.b * P * p.C, 0, (int)(P * p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t f2b = __builtin_amdgcn_make_buffer_rsrc(
+        p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C, 0, t.HWl * p.C * 4, 0x00020000);
     float* __restrict__ df1b = p.df1 + (size_t)t.b * P * p.C;
     float* __restrict__ df2b = p.df2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
     const int q_off = query_offset(p, t, tid & 31);
     const int q_stage = query_offset(p, t, tid >> 3);
-    const float* __restrict__ dout = p.dout + ((size_t)t.b * p.L + t.l) * rd2 * P;
+    const float* __restrict__ dout = p.dout + (((size_t)t.b * p.Nc + t.n) * p.L + t.l) * rd2 * P;
     const float inv_div = 1.0f / p.out_div;
     const int nk = (p.C + KC - 1) / KC;
 
@@ -327,7 +353,7 @@ void alt_tile_bwd_kernel(AltTileArgs p)
         }
         const int ulive = min(t.U - ubase - wave * 64, 64);        // box targets of this wave, wave-uniform
         Stage st;
-        stage_load(st, f1b, f2b, 0, p.C, p.vec, sh.toff, q_stage);
+        stage_load<VEC>(st, f1b, f2b, 0, p.C, sh.toff, q_stage);
         for (int kc = 0; kc < nk; ++kc) {
             const int c0 = kc * KC;
             __syncthreads();
@@ -335,7 +361,7 @@ void alt_tile_bwd_kernel(AltTileArgs p)
 #pragma unroll
             for (int i = 0; i < TQ * KC / 256; ++i) red[((tid >> 5) + 8 * i) * LDQ + (tid & 31)] = 0.f;
             __syncthreads();
-            if (kc + 1 < nk) stage_load(st, f1b, f2b, c0 + KC, p.C, p.vec, sh.toff, q_stage);
+            if (kc + 1 < nk) stage_load<VEC>(st, f1b, f2b, c0 + KC, p.C, sh.toff, q_stage);
             if (ulive > 0) {
                 // d(fmap1)[q][c] += sum over this wave's box targets   (rows q, lanes c)
                 v16f acc = {0};
@@ -384,33 +410,88 @@ void alt_tile_bwd_kernel(AltTileArgs p)
 int tile_prepare(AltTileArgs& a, const char* who)
 {
     if (a.r > 7) return fail(RAFTCORR_EUNSUPPORTED, "%s: radius %d > 7", who, a.r);
+    int64_t cells = (int64_t)a.H * a.W;
+    for (int l = 0; l < a.L; ++l) cells = std::max<int64_t>(cells, (int64_t)a.f2.g[l].h * a.f2.g[l].w);
+    if (cells * a.C * 4 >= (int64_t)1 << 31)
+        return fail(RAFTCORR_EUNSUPPORTED, "%s: a feature map of %lld x %d floats exceeds 2 GiB", who,
+                    (long long)cells, a.C);
     const int tiles = ((a.W + TQW - 1) / TQW) * ((a.H + TQH - 1) / TQH);
     a.band = (tiles + 7) / 8;
     bool aligned = ((uintptr_t)a.f1 & 15) == 0;
     for (int l = 0; l < a.L; ++l) aligned = aligned && ((uintptr_t)a.f2.ptr[l] & 15) == 0;
     a.vec = (a.C % 4 == 0) && aligned;
-    a.out_div = sqrtf((float)a.C);
     return RAFTCORR_OK;
 }
 
-dim3 tile_grid(const AltTileArgs& a) { return dim3(8u * a.band * a.L * a.B); }
+dim3 tile_grid(const AltTileArgs& a) { return dim3(8u * a.band * a.L * a.B * a.Nc); }
+
+int run_fwd(AltTileArgs& a, const char* who, hipStream_t s)
+{
+    int rc = tile_prepare(a, who);
+    if (rc) return rc;
+    const int rd = 2 * a.r + 1;
+    const bool small = TQ * rd * rd <= 256 * 11;
+    if (small && a.vec)       hipLaunchKernelGGL((alt_tile_fwd_kernel<11, true>), tile_grid(a), dim3(256), 0, s, a);
+    else if (small)           hipLaunchKernelGGL((alt_tile_fwd_kernel<11, false>), tile_grid(a), dim3(256), 0, s, a);
+    else if (a.vec)           hipLaunchKernelGGL((alt_tile_fwd_kernel<29, true>), tile_grid(a), dim3(256), 0, s, a);
+    else                      hipLaunchKernelGGL((alt_tile_fwd_kernel<29, false>), tile_grid(a), dim3(256), 0, s, a);
+    return check_launch("alt_tile_fwd_kernel");
+}
+
+// zeroes d(fmap1) (and d(fmap2) of every level when zero_df2) and accumulates into them
+int run_bwd(AltTileArgs& a, bool zero_df2, const char* who, hipStream_t s)
+{
+    int rc = tile_prepare(a, who);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(a.df1, 0, sizeof(float) * (size_t)a.B * a.C * a.H * a.W, s);
+    for (int l = 0; zero_df2 && l < a.L && e == hipSuccess; ++l)
+        e = hipMemsetAsync(a.df2.ptr[l], 0, sizeof(float) * (size_t)a.B * a.C * a.df2.g[l].h * a.df2.g[l].w, s);
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
+    if (a.vec) hipLaunchKernelGGL(alt_tile_bwd_kernel<true>, tile_grid(a), dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL(alt_tile_bwd_kernel<false>, tile_grid(a), dim3(256), 0, s, a);
+    return check_launch("alt_tile_bwd_kernel");
+}
 
 }  // namespace
 
+// ---- one level, the reference's pybind surface (unscaled, coords (B,N,H1,W1,2)) ----------------
+int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, float* corr,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s)
+{
+    AltTileArgs a = {};
+    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.g[0].h = H2; a.f2.g[0].w = W2;
+    a.coords = coords; a.out = corr;
+    a.B = B; a.Nc = N; a.C = C; a.H = H1; a.W = W1; a.L = 1; a.r = r;
+    a.planar = 0; a.level_scale = 0; a.out_div = 1.0f;
+    return run_fwd(a, "alt_forward", s);
+}
+
+int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,
+                         float* g1, float* g2, float* gc,
+                         int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s)
+{
+    if (gc) {
+        hipError_t e = hipMemsetAsync(gc, 0, sizeof(float) * (size_t)B * N * H1 * W1 * 2, s);
+        if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_backward: memset: %s", hipGetErrorString(e));
+    }
+    AltTileArgs a = {};
+    a.f1 = f1; a.f2.ptr[0] = const_cast<float*>(f2); a.f2.g[0].h = H2; a.f2.g[0].w = W2;
+    a.df2.ptr[0] = g2; a.df2.g[0].h = H2; a.df2.g[0].w = W2;
+    a.coords = coords; a.dout = cg; a.df1 = g1;
+    a.B = B; a.Nc = N; a.C = C; a.H = H1; a.W = W1; a.L = 1; a.r = r;
+    a.planar = 0; a.level_scale = 0; a.out_div = 1.0f;
+    return run_bwd(a, true, "alt_backward", s);
+}
+
+// ---- all levels fused (AlternateCorrBlock.__call__) -------------------------------------------
 int launch_alt_lookup_fwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
                           int r, const float* coords, float* out, hipStream_t s)
 {
     AltTileArgs a = {};
     a.f1 = f1; a.f2 = f2lv; a.coords = coords; a.out = out;
-    a.B = B; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
-    int rc = tile_prepare(a, "alt_lookup_fwd");
-    if (rc) return rc;
-    const int rd = 2 * r + 1;
-    if (TQ * rd * rd <= 256 * 11)
-        hipLaunchKernelGGL(alt_tile_fwd_kernel<11>, tile_grid(a), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(alt_tile_fwd_kernel<29>, tile_grid(a), dim3(256), 0, s, a);
-    return check_launch("alt_tile_fwd_kernel");
+    a.B = B; a.Nc = 1; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
+    a.planar = 1; a.level_scale = 1; a.out_div = sqrtf((float)C);
+    return run_fwd(a, "alt_lookup_fwd", s);
 }
 
 int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
@@ -419,13 +500,9 @@ int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, i
 {
     AltTileArgs a = {};
     a.f1 = f1; a.f2 = f2lv; a.df2 = df2lv; a.coords = coords; a.dout = dout; a.df1 = df1;
-    a.B = B; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
-    int rc = tile_prepare(a, "alt_lookup_bwd");
-    if (rc) return rc;
-    hipError_t e = hipMemsetAsync(df1, 0, sizeof(float) * (size_t)B * C * H * W, s);
-    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_lookup_bwd: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(alt_tile_bwd_kernel, tile_grid(a), dim3(256), 0, s, a);
-    return check_launch("alt_tile_bwd_kernel");
+    a.B = B; a.Nc = 1; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
+    a.planar = 1; a.level_scale = 1; a.out_div = sqrtf((float)C);
+    return run_bwd(a, false, "alt_lookup_bwd", s);
 }
 
 }  // namespace raftcorr

@@ -73,7 +73,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, -1, 8, 0, 8, None) == -1
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, 4, 8, 7, 8, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 0, 4, None) == -1
-    assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 4096, 4, None) == -2
+    assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 16, 8, None) == -2   # radius > 7
 
 
 def test_host_classes_validate_before_any_launch():
