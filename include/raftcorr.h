@@ -74,6 +74,17 @@ int raftcorr_build_pyramid(const float* fmap1, const float* fmap2,
                            float* const* levels, void* workspace, int64_t workspace_bytes,
                            void* stream);
 
+/* Same call with the operands of the contraction rounded to bfloat16 (round-to-nearest-even)
+ * and the products accumulated in fp32 on the bf16 matrix cores; the pyramid is fp32 as above.
+ * This is the "mixed precision" build (the reference runs its encoders under autocast,
+ * core/raft.py:99-103, and the north star's bf16 option): results differ from the fp32 build
+ * by the input rounding only (<= 1e-2 relative; typically 2e-3 of max|level0| at D = 256).
+ * Same workspace size as raftcorr_build_pyramid. */
+int raftcorr_build_pyramid_bf16(const float* fmap1, const float* fmap2,
+                                int B, int D, int H, int W, int num_levels,
+                                float* const* levels, void* workspace, int64_t workspace_bytes,
+                                void* stream);
+
 /* Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
  * core/utils/utils.py:57-65): for every query q and level l the (2r+1)^2 window of 4-tap
  * bilinear samples (zero padding) of levels[l][b*N+q] at (x + a - r, y + b - r); output channel

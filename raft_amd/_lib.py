@@ -29,6 +29,9 @@ _SIGNATURES = {
     "raftcorr_build_pyramid": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                 ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
                                 ctypes.c_void_p], _c_int),
+    "raftcorr_build_pyramid_bf16": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
+                                     ctypes.c_void_p], _c_int),
     "raftcorr_lookup_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),
     "raftcorr_lookup_bwd": ([ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),

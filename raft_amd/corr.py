@@ -119,17 +119,17 @@ class _Pyramid:
         self.dptrs = None
 
 
-def _build(fmap1, fmap2, pyr):
+def _build(fmap1, fmap2, pyr, precision="fp32"):
     lib = _lib.load()
+    entry = lib.raftcorr_build_pyramid_bf16 if precision == "bf16" else lib.raftcorr_build_pyramid
     B, D, H, W = fmap1.shape
     flat = torch.empty(pyr.total, dtype=torch.float32, device=fmap1.device)
     pyr.attach(flat)
     wbytes = lib.raftcorr_build_workspace_bytes(B, D, H, W)
     work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
     with _guard(fmap1):
-        _lib.check(lib.raftcorr_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
-                                              pyr.ptrs, work.data_ptr(), wbytes, _stream(fmap1)),
-                   "build_pyramid")
+        _lib.check(entry(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
+                         pyr.ptrs, work.data_ptr(), wbytes, _stream(fmap1)), "build_pyramid")
     return flat
 
 
@@ -139,8 +139,8 @@ class _BuildPyramid(torch.autograd.Function):
     gradient per lookup (the lookups write into pyr.dflat and return a zero anchor gradient)."""
 
     @staticmethod
-    def forward(ctx, fmap1, fmap2, pyr):
-        flat = _build(fmap1, fmap2, pyr)
+    def forward(ctx, fmap1, fmap2, pyr, precision):
+        flat = _build(fmap1, fmap2, pyr, precision)
         ctx.save_for_backward(fmap1, fmap2)
         ctx.pyr = pyr
         ctx.set_materialize_grads(False)
@@ -155,7 +155,7 @@ class _BuildPyramid(torch.autograd.Function):
             acc = pyr.grad_buffer()
             acc += dflat
         if pyr.dflat is None:
-            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None
         lib = _lib.load()
         B, D, H, W = fmap1.shape
         d1 = torch.empty_like(fmap1)
@@ -167,7 +167,7 @@ class _BuildPyramid(torch.autograd.Function):
                                               pyr.dptrs, d1.data_ptr(), d2.data_ptr(), work.data_ptr(),
                                               wbytes, _stream(fmap1)), "build_bwd")
         pyr.release_grad()                          # level 0 was clobbered by the fold
-        return d1, d2, None
+        return d1, d2, None, None
 
 
 def _lookup(pyr, coords, radius, mode):
@@ -213,11 +213,19 @@ class _Lookup(torch.autograd.Function):
 
 class CorrBlock:
     """All-pairs correlation volume + pooled pyramid + radius-r bilinear lookup.
-    Drop-in for core/corr.py:12-61 (same constructor defaults: num_levels=2, radius=4)."""
+    Drop-in for core/corr.py:12-61 (same constructor defaults: num_levels=2, radius=4).
 
-    def __init__(self, fmap1, fmap2, num_levels=2, radius=4):
+    precision (keyword, not in the reference): "fp32" (default; parity with the reference to
+    1e-5) or "bf16" -- the contraction's operands are rounded to bfloat16 and accumulated in fp32
+    on the bf16 matrix cores (the pyramid, the lookup and the backward pass stay fp32; the
+    backward is that of the fp32 function).  Results differ by the input rounding, <= 1e-2."""
+
+    def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32"):
         self.num_levels = num_levels
         self.radius = radius
+        if precision not in ("fp32", "bf16"):
+            raise RuntimeError(f"CorrBlock: precision must be 'fp32' or 'bf16'; got {precision!r}")
+        self.precision = precision
         _require_cuda(fmap1=fmap1, fmap2=fmap2)
         if fmap1.dim() != 4 or fmap1.shape != fmap2.shape:
             raise RuntimeError(f"CorrBlock: fmap1/fmap2 must both be (B, D, H, W); got "
@@ -230,10 +238,10 @@ class CorrBlock:
         B, D, H, W = fmap1.shape
         self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device)
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
-            flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr)
+            flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr, precision)
             self._pyr.flat = flat.detach()
         else:
-            flat = _build(fmap1, fmap2, self._pyr)
+            flat = _build(fmap1, fmap2, self._pyr, precision)
             self._anchor = None
         self._flat = flat            # packed levels (autograd-tracked when the features are)
         self._logical = None

@@ -24,6 +24,7 @@
 //           row_ror:8); level 3: one cross-row swizzle.  Sums are scaled by exact powers of
 //           two, so the values equal avg_pool2d's up to the order of the three additions.
 #include "common.h"
+#include <stdlib.h>
 
 namespace raftcorr {
 
@@ -102,6 +103,7 @@ struct BuildArgs {
     long long slab[4];    // elements per query slab, levels 0..3
     int B, Dpad, N, L;
     int tilesM, tilesN, nblk_per_b, PW;
+    int group_m;          // query tiles walked together (L2 reuse of the operand panels)
     float inv_sqrt_d;     // used when sqrt(D) is a power of two (exact)
     float sqrt_d;         // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
 };
@@ -123,97 +125,35 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_chunk)
                                      (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
 }
 
-template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD)
-void corr_build_f32_kernel(BuildArgs p)
+// ---- block -> (batch, query tile, patch), XCD-aware ------------------------------------
+// Blocks are dealt round-robin over the 8 XCDs; give every XCD a contiguous chunk of the
+// tile list (bijective form, any grid size) and walk it GROUP_M query tiles at a time, so
+// the blocks resident together on one XCD share a few A and B panels in its L2.
+__device__ __forceinline__ void block_to_tile(const BuildArgs& p, int& b, int& tm, int& tn)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];   // [buf][A|B][k][128]
-
-    // ---- block -> (batch, query tile, patch), XCD-aware ----------------------------------
-    // Blocks are dealt round-robin over the 8 XCDs; give every XCD a contiguous chunk of the
-    // tile list (bijective form, any grid size) and walk it GROUP_M query tiles at a time, so
-    // the blocks resident together on one XCD share a few A and B panels in its L2.
     const int nwg = gridDim.x;
     const int orig = blockIdx.x;
     const int xcd = orig & 7;
     const int qd = nwg >> 3, rm = nwg & 7;
     const int lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-    const int b = lin / p.nblk_per_b;
+    b = lin / p.nblk_per_b;
     const int t = lin - b * p.nblk_per_b;
-    const int per_group = GROUP_M * p.tilesN;
+    const int per_group = p.group_m * p.tilesN;
     const int grp = t / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(GROUP_M, p.tilesM - first_m);
+    const int first_m = grp * p.group_m;
+    const int gsz = min(p.group_m, p.tilesM - first_m);
     const int within = t - grp * per_group;
-    const int tm = first_m + within % gsz;
-    const int tn = within / gsz;
-    const int m0 = tm * BM;
+    tm = first_m + within % gsz;
+    tn = within / gsz;
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Dpad = p.Dpad;
-
-    const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * Dpad * 128;
-    const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * Dpad * 128;
-
-    // stage K tile kt into LDS buffer buf: BK x 512 B of A and of B, BK/8 + BK/8 DMA pieces per wave
-    auto stage = [&](int kt, int buf) {
-        float* la = smem + buf * (2 * BK * 128);
-        float* lb = la + BK * 128;
-        const float* ga = pa + (size_t)kt * BK * 128;
-        const float* gb = pb + (size_t)kt * BK * 128;
-#pragma unroll
-        for (int i = 0; i < BK / 8; ++i) {
-            const int piece = wave * (BK / 8) + i;       // 1 KiB pieces, BK/2 per operand tile
-            glds16(ga + piece * 256 + lane * 4, la + piece * 256);
-            glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
-        }
-    };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-
-    const int nk = Dpad / BK;
-    const int kh = lane >> 5;       // which of the 2 k rows of an MFMA step this lane feeds
-    const int l31 = lane & 31;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        __syncthreads();            // tile kt has landed (vmcnt(0) precedes the barrier) and
-                                    // nobody still reads the buffer that is restaged next
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const float* la = smem + buf * (2 * BK * 128) + kh * 128 + wave * 32 + l31;
-        const float* lb = smem + buf * (2 * BK * 128) + BK * 128 + kh * 128 + l31 * 4;
-        float a_cur = la[0];
-        float4 b_cur = *(const float4*)lb;
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a_nxt = 0.f;
-            float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk + 1 < BK / 2) {
-                a_nxt = la[(kk + 1) * 256];
-                b_nxt = *(const float4*)(lb + (kk + 1) * 256);
-            }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.w, acc[3], 0, 0, 0);
-            a_cur = a_nxt;
-            b_cur = b_nxt;
-        }
-    }
-
-#if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
-    return;
-#endif
+// Shared by the fp32 and bf16 kernels (both MFMAs have the same 32x32 C/D map): scale, store
+// level 0, pool levels 1..3 out of the accumulators.
+template <bool EXACT_MUL>
+__device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)[4], int b, int tn, int m0,
+                                               int wave, int lane)
+{
+    const int kh = lane >> 5, l31 = lane & 31;
     // ---- epilogue ------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Stores go through buffer descriptors that cover exactly this wave's valid query rows:
@@ -287,6 +227,206 @@ void corr_build_f32_kernel(BuildArgs p)
     }
 }
 
+template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD)
+void corr_build_f32_kernel(BuildArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];   // [buf][A|B][k][128]
+
+    int b, tm, tn;
+    block_to_tile(p, b, tm, tn);
+    const int m0 = tm * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Dpad = p.Dpad;
+
+    const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * Dpad * 128;
+    const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * Dpad * 128;
+
+    // stage K tile kt into LDS buffer buf: BK x 512 B of A and of B, BK/8 + BK/8 DMA pieces per wave
+    auto stage = [&](int kt, int buf) {
+        float* la = smem + buf * (2 * BK * 128);
+        float* lb = la + BK * 128;
+        const float* ga = pa + (size_t)kt * BK * 128;
+        const float* gb = pb + (size_t)kt * BK * 128;
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) {
+            const int piece = wave * (BK / 8) + i;       // 1 KiB pieces, BK/2 per operand tile
+            glds16(ga + piece * 256 + lane * 4, la + piece * 256);
+            glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+    const int nk = Dpad / BK;
+    const int kh = lane >> 5;       // which of the 2 k rows of an MFMA step this lane feeds
+    const int l31 = lane & 31;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();            // tile kt has landed (vmcnt(0) precedes the barrier) and
+                                    // nobody still reads the buffer that is restaged next
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const float* la = smem + buf * (2 * BK * 128) + kh * 128 + wave * 32 + l31;
+        const float* lb = smem + buf * (2 * BK * 128) + BK * 128 + kh * 128 + l31 * 4;
+        float a_cur = la[0];
+        float4 b_cur = *(const float4*)lb;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a_nxt = 0.f;
+            float4 b_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk + 1 < BK / 2) {
+                a_nxt = la[(kk + 1) * 256];
+                b_nxt = *(const float4*)(lb + (kk + 1) * 256);
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur.w, acc[3], 0, 0, 0);
+            a_cur = a_nxt;
+            b_cur = b_nxt;
+        }
+    }
+
+#if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
+    return;
+#endif
+    build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16-operand variant: the same tiling and the same epilogue, operands rounded to bf16 (RNE) by
+// the pack pass, products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA
+// rate), pyramid written in fp32 as before.  The contraction stops being the bottleneck: the
+// kernel runs at the speed of its 1.33 x 4 N^2 bytes of stores.
+//
+// Operand panels, per tile:  [k-step (16 k)][h = k half][column 128][8 bf16]   (16 B per lane)
+//   lane (r = l & 31, h = l >> 5) of the MFMA holds A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
+//   A columns = the tile's queries; B columns = n*32 + j  (accumulator n, MFMA column j).
+// A K tile of BK16 = 32 k is 8 KiB per operand, contiguous in the panel: staged exactly like the
+// fp32 kernel's (two 1 KiB DMA pieces per wave and operand).
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK16 = 32;
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// grid (tilesM + tilesN, PACK_KSPLIT, B); thread = one column x (Dpad/8/PACK_KSPLIT/2) groups of 8 k
+__global__ __launch_bounds__(256)
+void corr_pack_bf16_kernel(PackArgs p)
+{
+    const int N = p.H * p.W;
+    const int c = threadIdx.x & 127, gp = threadIdx.x >> 7;
+    const int b = blockIdx.z;
+    int tile = blockIdx.x;
+    const bool second = tile >= p.tilesM;
+    int t = -1;
+    if (!second) {
+        const int q = tile * 128 + c;
+        if (q < N) t = q;
+    } else {
+        tile -= p.tilesM;
+        const int PW = patches_w(p.W);
+        const int n = c >> 5, j = c & 31;                                     // column = n*32 + j
+        const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
+        const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
+        const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
+        const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
+        if (y < p.H && x < p.W) t = y * p.W + x;
+    }
+    const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
+    uint4* __restrict__ dst = (uint4*)(second ? p.f2p : p.f1p) +
+                              ((size_t)b * (second ? p.tilesN : p.tilesM) + tile) * (p.Dpad / 8) * 128 + c;
+    const int groups = p.Dpad / 8, per = groups / PACK_KSPLIT;                // Dpad is a multiple of 64
+    for (int g = blockIdx.y * per + gp; g < (blockIdx.y + 1) * per; g += 2) {
+        unsigned short h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = g * 8 + j;
+            h[j] = f32_to_bf16_rne((t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f);
+        }
+        uint4 w;
+        w.x = h[0] | ((unsigned)h[1] << 16); w.y = h[2] | ((unsigned)h[3] << 16);
+        w.z = h[4] | ((unsigned)h[5] << 16); w.w = h[6] | ((unsigned)h[7] << 16);
+        dst[(size_t)g * 128] = w;                                             // [g = 2*kstep + h][column][8]
+    }
+}
+
+template <bool EXACT_MUL>
+__global__ __launch_bounds__(256, 3)
+void corr_build_bf16_kernel(BuildArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 2048];       // [buf][A|B][8 KiB]
+
+    int b, tm, tn;
+    block_to_tile(p, b, tm, tn);
+    const int m0 = tm * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int panel = p.Dpad * 64;                                        // floats per panel (Dpad * 128 bf16)
+    const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * panel;
+    const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * panel;
+
+    auto stage = [&](int kt, int buf) {
+        float* la = smem + buf * 4096;
+        float* lb = la + 2048;
+        const float* ga = pa + (size_t)kt * 2048;
+        const float* gb = pb + (size_t)kt * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;
+            glds16(ga + piece * 256 + lane * 4, la + piece * 256);
+            glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+    const int nk = p.Dpad / BK16;
+    const int kh = lane >> 5, l31 = lane & 31;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        // fragment of k-step s: 16-byte slot ((2s + kh) * 128 + column)
+        const bf16x8* la = (const bf16x8*)(smem + buf * 4096) + kh * 128 + wave * 32 + l31;
+        const bf16x8* lb = (const bf16x8*)(smem + buf * 4096 + 2048) + kh * 128 + l31;
+#pragma unroll
+        for (int s = 0; s < BK16 / 16; ++s) {
+            const bf16x8 a = la[s * 256];
+            const bf16x8 b0 = lb[s * 256], b1 = lb[s * 256 + 32], b2 = lb[s * 256 + 64], b3 = lb[s * 256 + 96];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3, acc[3], 0, 0, 0);
+        }
+    }
+    build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
+}
+
 // levels >= 4: 2x2 mean of the previous level (rare: RAFT uses 4 levels); output row-major
 __global__ void pool2x2_kernel(const float* __restrict__ in, float* __restrict__ out, size_t M,
                                LevelGeom gi, LevelGeom go)
@@ -308,27 +448,39 @@ __global__ void pool2x2_kernel(const float* __restrict__ in, float* __restrict__
 size_t build_workspace_bytes(int B, int D, int H, int W)
 {
     const int N = H * W;
-    const size_t Dpad = (size_t)(D + 31) / 32 * 32;
+    const size_t Dpad = (size_t)(D + 63) / 64 * 64;
     const size_t tilesM = (N + BM - 1) / BM, tilesN = (size_t)patches_h(H) * patches_w(W);
     return (size_t)B * Dpad * 128 * (tilesM + tilesN) * sizeof(float);
 }
 
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, void* workspace, size_t workspace_bytes, hipStream_t s)
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, bool bf16, hipStream_t s)
 {
     if (workspace_bytes < build_workspace_bytes(B, D, H, W) || !workspace)
         return fail(RAFTCORR_EINVAL, "build_pyramid: workspace too small (%zu < %zu bytes)",
                     workspace_bytes, build_workspace_bytes(B, D, H, W));
     BuildArgs a;
     a.B = B; a.N = H * W; a.L = L < 4 ? L : 4;
-    a.Dpad = (D + 31) / 32 * 32;             // multiple of every BK the kernel is instantiated for
+    a.Dpad = (D + 63) / 64 * 64;             // multiple of every K tile and of the pack kernels' k split
     a.tilesM = (a.N + BM - 1) / BM;
     a.tilesN = patches_h(H) * patches_w(W);
     a.PW = patches_w(W);
+    // bf16 on volumes far beyond the 256 MB infinity cache is bound by HBM write efficiency: one
+    // query tile at a time per XCD keeps each row's concurrently written segment long (measured at
+    // 1080p: 1.61 ms vs 2.35 ms with groups of 8; at Sintel size the grouping of 8 is the faster one)
+    a.group_m = (bf16 && (double)B * a.N * (double)lv.g[0].slab * 4.0 > 1.0e9) ? 1 : GROUP_M;
+    if (const char* e = getenv("RC_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : GROUP_M;   // lab knob
     a.nblk_per_b = a.tilesM * a.tilesN;
     float* f1p = (float*)workspace;
-    float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * 128;
-    int rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
+    float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * (bf16 ? 64 : 128);
+    int rc;
+    if (bf16) {
+        PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN};
+        hipLaunchKernelGGL(corr_pack_bf16_kernel, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
+        rc = check_launch("corr_pack_bf16_kernel");
+    } else {
+        rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
+    }
     if (rc) return rc;
     a.f1p = f1p; a.f2p = f2p;
     for (int l = 0; l < 4; ++l) {
@@ -345,9 +497,14 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     const long long nblk = (long long)a.nblk_per_b * B;
     if (nblk > 0x7fffffffLL) return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: grid too large");
     dim3 grid((unsigned)nblk), block(256);
-    if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);
-    else       hipLaunchKernelGGL((corr_build_f32_kernel<false, BK, WPS>), grid, block, 0, s, a);
-    rc = check_launch("corr_build_f32_kernel");
+    if (bf16) {
+        if (exact) hipLaunchKernelGGL(corr_build_bf16_kernel<true>, grid, block, 0, s, a);
+        else       hipLaunchKernelGGL(corr_build_bf16_kernel<false>, grid, block, 0, s, a);
+    } else {
+        if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);
+        else       hipLaunchKernelGGL((corr_build_f32_kernel<false, BK, WPS>), grid, block, 0, s, a);
+    }
+    rc = check_launch(bf16 ? "corr_build_bf16_kernel" : "corr_build_f32_kernel");
     if (rc) return rc;
     for (int l = 4; l < L; ++l) {
         const size_t M = (size_t)B * a.N;

@@ -196,6 +196,32 @@ def test_pyramid_tensors_are_differentiable(dev):
     assert rel_err(g1, o1) <= GTOL and rel_err(g2, o2) <= GTOL
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 55, 128), (2, 128, 17, 20), (1, 40, 13, 19)])
+def test_bf16_build_option(shape, dev):
+    """precision="bf16": operands rounded to bfloat16 (RNE), fp32 accumulation, fp32 pyramid.
+    (i) equals the fp32 oracle run on bf16-rounded inputs to fp32 accuracy (1e-5), i.e. the only
+    difference to the reference is the input rounding; (ii) within the north star's bf16
+    tolerance (1e-2 relative) of the unrounded fp32 oracle, pyramid and lookup."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    B, D, H, W = shape
+    L, r = 3, 4
+    rs = np.random.RandomState(sum(shape))
+    f1 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    f2 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    co = torch.from_numpy((rs.rand(B, 2, H, W) * [[[W + 4]], [[H + 4]]] - 2).astype(np.float32))
+    cb = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r, precision="bf16")
+    out = cb(co.to(dev)).cpu().numpy()
+    rounded = O.CorrBlockOracle(f1.bfloat16().float(), f2.bfloat16().float(), L, r)
+    exact = O.CorrBlockOracle(f1, f2, L, r)
+    for l in range(L):
+        got = cb.corr_pyramid[l].cpu().numpy()
+        assert rel_err(got, rounded.corr_pyramid[l].numpy()) <= TOL
+        assert rel_err(got, exact.corr_pyramid[l].numpy()) <= 1e-2
+    assert rel_err(out, rounded(co).numpy()) <= TOL
+    assert rel_err(out, exact(co).numpy()) <= 1e-2
+
+
 # ---------------------------------------------------------------------------------------
 # on-the-fly ("alternate") path
 # ---------------------------------------------------------------------------------------

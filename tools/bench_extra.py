@@ -56,6 +56,25 @@ def alt_fb_s():
     f1g.grad = None; f2g.grad = None
     AlternateCorrBlock(f1g, f2g, 4, 4)(co_s).backward(gout)
 res["kitti_alt_fwd_bwd_smooth_us"] = ev_time(alt_fb_s, reps=5, warm=2)
+# bf16-operand build at the headline shape (Sintel 55x128) and at config 5's 1080p shape
+for tag, (Hs, Ws) in {"sintel": (55, 128), "1080p": (136, 240)}.items():
+    a = torch.randn(1, 256, Hs, Ws, generator=g).to(dev); bb = torch.randn(1, 256, Hs, Ws, generator=g).to(dev)
+    with torch.no_grad():
+        res[f"{tag}_build_fp32_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4), reps=10)
+        res[f"{tag}_build_bf16_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4, precision="bf16"), reps=10)
+        cbx = CorrBlock(a, bb, 4, 4)
+        cox = coords_for(1, Hs, Ws, 3.0, g)
+        res[f"{tag}_lookup_us"] = ev_time(lambda: cbx(cox))
+        blkx = AlternateCorrBlock(a, bb, 4, 4)
+        res[f"{tag}_alt_fwd_us"] = ev_time(lambda: blkx(cox), reps=10)
+        del cbx
+# achievable HBM rates on this box (quote fractions of nominal and of achievable)
+big = torch.empty(1 << 30, dtype=torch.float32, device=dev)          # 4 GiB
+big2 = torch.empty(1 << 30, dtype=torch.float32, device=dev)
+res["hbm_fill_GBs"] = big.numel() * 4 / ev_time(lambda: big.zero_(), reps=5) / 1e3
+res["hbm_copy_GBs"] = 2 * big.numel() * 4 / ev_time(lambda: big2.copy_(big), reps=5) / 1e3
+res["hbm_read_GBs"] = big.numel() * 4 / ev_time(lambda: big.sum(), reps=5) / 1e3
+del big, big2
 # config 4: FlyingThings crops B=6, 12 lookups fwd + bwd
 B, D, H, W = 6, 256, 50, 90
 f1 = torch.randn(B, D, H, W, generator=g).to(dev).requires_grad_(True)
