@@ -17,6 +17,9 @@ max-over-ranks of the elapsed time.
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel's achieved rate vs the MI355X peak (HIP events, live)
   kernels       the same figures for both kernels of the step (build: MFMA, lookup: HBM)
+  extras        (N = 1 only, outside the timed region) the other kernels of the path at the same
+                shape -- bf16-operand build, on-the-fly lookup -- and the box's achievable HBM
+                rates (fill / copy), so fractions can be read against nominal and achievable
   cpu_baseline  the CPU oracle (stock PyTorch CPU ops in the reference's order) timed on this
                 host on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -33,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from raft_amd import CorrBlock, _lib       # noqa: E402
+from raft_amd import AlternateCorrBlock, CorrBlock, _lib       # noqa: E402
 from raft_amd.sharding import max_over_ranks   # noqa: E402
 
 # workload: BASELINE.json configs[1]
@@ -79,7 +82,47 @@ def one_pair(f1, f2, coords):
     return out
 
 
-def cpu_baseline(seed, budget_s=20.0):
+def ev_time_us(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def extras(f1, f2, coords, dev):
+    """Untimed side measurements at the workload's shape."""
+    N, T = H * W, 2 * RADIUS + 2
+    bf, bb, _ = algorithmic_work()
+    out = {}
+    with torch.no_grad():
+        t = ev_time_us(lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="bf16"))
+        out["build_bf16"] = {"kernel": "corr_build_bf16_kernel (+ pack)", "us_per_launch": t, "bound": "hbm",
+                             "achieved": bb / t / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bb / t / 1e3 / HBM_PEAK_GBS, "algorithmic_bytes": bb,
+                             "TFLOPs": bf / t / 1e6}
+        alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
+        alt_flops = 2.0 * B * N * LEVELS * T * T * D
+        alt_bytes = 4.0 * (B * N * D + sum(B * (H >> l) * (W >> l) * D for l in range(LEVELS)) + 2 * B * N +
+                           B * N * LEVELS * (2 * RADIUS + 1) ** 2)
+        for tag, c in (("alt_fwd_iter0", coords[0]), ("alt_fwd_iter8", coords[8])):
+            t = ev_time_us(lambda: alt(c))
+            out[tag] = {"kernel": "alt_tile_fwd_kernel", "us_per_launch": t,
+                        "algorithmic_TFLOPs": alt_flops / t / 1e6, "compulsory_GBs": alt_bytes / t / 1e3,
+                        "note": "identity flow" if tag.endswith("0") else "flow = 8 steps of N(0, 3^2) drift per pixel"}
+        big = torch.empty(1 << 28, dtype=torch.float32, device=dev)        # 1 GiB
+        big2 = torch.empty_like(big)
+        out["hbm_achievable_GBs"] = {"fill": big.numel() * 4 / ev_time_us(lambda: big.zero_(), 5) / 1e3,
+                                     "copy": 2 * big.numel() * 4 / ev_time_us(lambda: big2.copy_(big), 5) / 1e3}
+    return out
+
+
+def cpu_baseline(seed, budget_s=15.0):
     """Oracle (= the reference's operator sequence on stock PyTorch CPU ops) on the same
     workload, bounded sample.  Checker code, timed beside the GPU -- never the product path."""
     from oracle import corr_oracle as O
@@ -95,7 +138,7 @@ def cpu_baseline(seed, budget_s=20.0):
                 cb(c)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s or n >= 20:
+            if el > budget_s or n >= 150:
                 break
     return {"value": n / el, "unit": "frame pairs/sec", "cores": cores, "kind": "port",
             "sample": f"{n} pair(s) of the same workload (build + {ITERS} lookups, 55x128, D=256, fp32) "
@@ -183,6 +226,8 @@ def main():
             "us_per_build": build_ms * 1e3, "us_per_lookup": lookup_ms * 1e3,
             "roofline": roofline, "kernels": {"build": k_build, "lookup": k_lookup},
         }
+        if args.gpus == 1:
+            line["extras"] = extras(f1, f2, coords, dev)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(1234)
         print(json.dumps(line), flush=True)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc CSVs (gpurun_out/pmc/*/**/*counter_collection.csv) per kernel:
 mean counter value per dispatch.  usage: python tools/pmc_summarize.py [dir] > profiles/xxx.txt"""
+import re
 import csv
 import glob
 import os
@@ -12,7 +13,9 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "raftcorr" not in row["Kernel_Name"]:
+                continue                                  # PyTorch's own kernels are not the subject
+            k = re.search(r"\w+_kernel(<[^>(]*>)?", row["Kernel_Name"]).group(0)
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)

@@ -3,14 +3,16 @@
 bytes per kernel = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024.  The factor 2 is the gfx950
 correction (MI355X_MICROARCH.md, HBM section; re-measured for sparse reads in
 profiles/r01_fetch_calibration.txt): FETCH_SIZE tallies each 128-B request at 64 B."""
-import csv, glob, json, os, sys
+import re, csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("::")[-1].split("<")[0]
+        if "raftcorr" not in row["Kernel_Name"]:
+            continue
+        k = re.search(r"\w+_kernel", row["Kernel_Name"]).group(0)
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, c in acc.items():
