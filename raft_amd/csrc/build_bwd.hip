@@ -10,6 +10,7 @@
 // arithmetic, and padding columns carry exact zeros (lookups never write them), so the fold
 // is an elementwise pass and the contractions run over the padded column range unchecked.
 #include "common.h"
+#include <algorithm>
 
 namespace raftcorr {
 
@@ -95,95 +96,188 @@ void corr_cols_scatter_back_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
-// C[m][n] = sum_k A[m][k] * Bm(k, n);  A row-major (lda, k contiguous);
-// Bm(k, n) = B[k*ldb + n] (B_N_CONTIG) or B[n*ldb + k] (k contiguous).
-// 64x64 block tile, 4 waves as 2x2, one 32x32 accumulator each, BK = 32.
+// C[m][n] (+)= sum_k A[m][k] * Bm(k, n);  A row-major (lda, k contiguous);
+// Bm(k, n) = B[n*ldb + k] (B_K_CONTIG) or B[k*ldb + n] (n contiguous).
+// 128x128 block tile, 4 waves as 2x2, each 64x64 = 2x2 accumulators of v_mfma_f32_32x32x2_f32,
+// K tile 32 (a row's share of a tile = one 128-B line).  Operands are fetched with branch-free
+// buffer loads (rows / k beyond the matrix read as zero), held in registers while the previous
+// tile is multiplied, and stored into LDS as [k][row] images whose reads and (transposed) writes
+// are both bank-conflict-free.  The K range can be split over gridDim.z (the feature-gradient
+// GEMMs have M = D = 256 only, i.e. few tiles and a long K): partial sums are then added with float
+// atomics into a zeroed C.
 struct GemmArgs {
     const float* A; const float* B; float* C;
     int M, N, K;
-    size_t lda, ldb, ldc;
-    size_t sA, sB, sC;   // batch strides
+    int lda, ldb, ldc;
+    size_t sA, sB, sC;   // batch strides (elements)
+    int ksplit, kper;    // gridDim.z = batch * ksplit; kper = K range per split (multiple of 32)
+    int vecA, vecB;      // 16-byte loads legal (alignment + extents)
 };
 
-template <bool B_N_CONTIG>
-__global__ __launch_bounds__(256)
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+constexpr unsigned GOOB = 0x80000000u;
+
+__device__ __forceinline__ float4 gemm_quad(__amdgpu_buffer_rsrc_t rs, bool row_ok, size_t row_off, int c, int C,
+                                            int vec)
+{
+    // 4 consecutive elements c..c+3 of a row (element offset row_off + c), zero beyond C / bad row
+    const unsigned base = (unsigned)((row_off + (size_t)c) * 4);
+    float4 v;
+    if (vec) {
+        const u32x4g w = __builtin_amdgcn_raw_buffer_load_b128(rs, (row_ok && c < C) ? base : GOOB, 0, 0);
+        v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    } else {
+        v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && c < C) ? base : GOOB, 0, 0));
+        v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && c + 1 < C) ? base + 4 : GOOB, 0, 0));
+        v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && c + 2 < C) ? base + 8 : GOOB, 0, 0));
+        v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && c + 3 < C) ? base + 12 : GOOB, 0, 0));
+    }
+    return v;
+}
+
+template <bool B_K_CONTIG>
+__global__ __launch_bounds__(256, 2)
 void gemm_f32_kernel(GemmArgs p)
 {
-    constexpr int TM = 64, TN = 64, TK = 32, LD = 65;
-    __shared__ float As[2][TK][LD];
-    __shared__ float Bs[2][TK][LD];
+    constexpr int TM = 128, TN = 128, TK = 32;
+    constexpr int LDT = TM + 1;          // transposed images ([k][row], written one scalar at a time)
+    constexpr int LDN = TN + 4;          // n-contiguous image (written as float4)
+    __shared__ __attribute__((aligned(16))) float As[TK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[TK * (B_K_CONTIG ? LDT : LDN)];
+    constexpr int LDB = B_K_CONTIG ? LDT : LDN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM, bz = blockIdx.z;
-    const float* __restrict__ A = p.A + bz * p.sA;
-    const float* __restrict__ B = p.B + bz * p.sB;
+    const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM;
+    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
+    const int M = p.M, N = p.N;
+    const float* __restrict__ Ab = p.A + bz * p.sA;
+    const float* __restrict__ Bb = p.B + bz * p.sB;
     float* __restrict__ C = p.C + bz * p.sC;
-    const int M = p.M, N = p.N, K = p.K;
+    // buffer descriptors are re-based on every K tile (tile origin), so offsets stay small
+    // whatever the matrix size; validity is decided per lane and spelled as an OOB offset
+    auto desc = [](const float* base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    };
 
-    float ra[8], rb[8];
+    float4 qa[4], qb[4];
     auto gload = [&](int k0) {
-        {   // A: lanes along k
-            const int kk = tid & 31, k = k0 + kk;
+        {   // A[m][k]: thread = (row tid>>3 + 32 i, k quad tid&7)
+            const __amdgpu_buffer_rsrc_t rs = desc(Ab + (size_t)m0 * p.lda + k0);
+            const int kq = 4 * (tid & 7);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + (tid >> 5) + 8 * i;
-                ra[i] = (m < M && k < K) ? A[(size_t)m * p.lda + k] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                qa[i] = gemm_quad(rs, m0 + r < M, (size_t)r * p.lda, kq, kend - k0, p.vecA);
             }
         }
-        if (B_N_CONTIG) {
-            const int n = n0 + (tid & 63);
+        if (B_K_CONTIG) {
+            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)n0 * p.ldb + k0);
+            const int kq = 4 * (tid & 7);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = k0 + (tid >> 6) + 4 * i;
-                rb[i] = (n < N && k < K) ? B[(size_t)k * p.ldb + n] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                qb[i] = gemm_quad(rs, n0 + r < N, (size_t)r * p.ldb, kq, kend - k0, p.vecB);
             }
-        } else {
-            const int kk = tid & 31, k = k0 + kk;
+        } else {        // B[k][n]: thread = (k row tid>>5 + 8 i, n quad tid&31)
+            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)k0 * p.ldb + n0);
+            const int nq = 4 * (tid & 31);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = n0 + (tid >> 5) + 8 * i;
-                rb[i] = (n < N && k < K) ? B[(size_t)n * p.ldb + k] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 5) + 8 * i;
+                qb[i] = gemm_quad(rs, k0 + r < kend, (size_t)r * p.ldb, nq, N - n0, p.vecB);
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&]() {
+        {
+            const int k = 4 * (tid & 7);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) As[buf][tid & 31][(tid >> 5) + 8 * i] = ra[i];
-        if (B_N_CONTIG) {
+            for (int i = 0; i < 4; ++i) {
+                float* d = As + k * LDT + (tid >> 3) + 32 * i;
+                d[0] = qa[i].x; d[LDT] = qa[i].y; d[2 * LDT] = qa[i].z; d[3 * LDT] = qa[i].w;
+            }
+        }
+        if (B_K_CONTIG) {
+            const int k = 4 * (tid & 7);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Bs[buf][(tid >> 6) + 4 * i][tid & 63] = rb[i];
+            for (int i = 0; i < 4; ++i) {
+                float* d = Bs + k * LDB + (tid >> 3) + 32 * i;
+                d[0] = qb[i].x; d[LDB] = qb[i].y; d[2 * LDB] = qb[i].z; d[3 * LDB] = qb[i].w;
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Bs[buf][tid & 31][(tid >> 5) + 8 * i] = rb[i];
+            for (int i = 0; i < 4; ++i)
+                *(float4*)(Bs + ((tid >> 5) + 8 * i) * LDB + 4 * (tid & 31)) = qb[i];
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nk = (K + TK - 1) / TK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     const int kh = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * TK);
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + TK < kend) gload(k0 + TK);
+        const float* la = As + kh * LDT + wm * 64 + l31;
+        const float* lb = Bs + kh * LDB + wn * 64 + l31;
 #pragma unroll
         for (int kk = 0; kk < TK / 2; ++kk) {
-            const float a = As[buf][2 * kk + kh][wm * 32 + l31];
-            const float b = Bs[buf][2 * kk + kh][wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const float a0 = la[2 * kk * LDT], a1 = la[2 * kk * LDT + 32];
+            const float b0 = lb[2 * kk * LDB], b1 = lb[2 * kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
     }
-    const int n = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-        if (m < M && n < N) C[(size_t)m * p.ldc + n] = acc[reg];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + l31;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                if (m < M && n < N) {
+                    if (p.ksplit > 1) atomicAdd(C + (size_t)m * p.ldc + n, acc[a][b][reg]);
+                    else C[(size_t)m * p.ldc + n] = acc[a][b][reg];
+                }
+            }
+        }
+}
+
+// fills the launch-shape fields and runs one batched GEMM; C is zeroed first when K is split
+template <bool B_K_CONTIG>
+static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
+{
+    if ((size_t)128 * std::max(a.lda, a.ldb) * 4 >= ((size_t)1 << 31))
+        return fail(RAFTCORR_EUNSUPPORTED, "%s: leading dimension too large", what);
+    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
+    int ksplit = 1;
+    while (tiles * ksplit < 512 && ksplit < 16 && a.K / (ksplit * 2) >= 256) ksplit *= 2;
+    a.ksplit = ksplit;
+    a.kper = (((a.K + ksplit - 1) / ksplit) + 31) / 32 * 32;
+    a.vecA = (a.lda % 4 == 0) && (a.K % 4 == 0) && (((uintptr_t)a.A | (a.sA * 4)) % 16 == 0);
+    a.vecB = (a.ldb % 4 == 0) && ((B_K_CONTIG ? a.K : a.N) % 4 == 0) && (((uintptr_t)a.B | (a.sB * 4)) % 16 == 0);
+    if (ksplit > 1) {
+        // C is (M x ldc) per image and fully owned by this GEMM
+        hipError_t e = hipSuccess;
+        if (a.sC == (size_t)a.M * a.ldc) e = hipMemsetAsync(a.C, 0, sizeof(float) * a.sC * batch, s);
+        else for (int b = 0; b < batch && e == hipSuccess; ++b)
+            e = hipMemsetAsync(a.C + b * a.sC, 0, sizeof(float) * (size_t)a.M * a.ldc, s);
+        if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     }
+    hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, dim3((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit),
+                       dim3(256), 0, s, a);
+    return check_launch(what);
 }
 
 size_t build_bwd_workspace_bytes(int B, int D, int H, int W)
@@ -238,20 +332,18 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     rc = check_launch("corr_cols_gather_kernel");
     if (rc) return rc;
 
-    GemmArgs a;
+    GemmArgs a = {};
     // dF1[d][q] = sum_p F2v[d][p] * dC0[q][p]      (B operand: k = p contiguous)
     a.A = f2v; a.B = dlv.ptr[0]; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
-    a.lda = S0; a.ldb = S0; a.ldc = N;
+    a.lda = (int)S0; a.ldb = (int)S0; a.ldc = N;
     a.sA = (size_t)D * S0; a.sB = (size_t)N * S0; a.sC = (size_t)D * N;
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((N + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, a);
-    rc = check_launch("gemm_f32_kernel<dF1>");
+    rc = run_gemm<true>(a, B, "gemm_f32_kernel<dF1>", s);
     if (rc) return rc;
     // dF2v[d][p] = sum_q F1[d][q] * dC0[q][p]      (B operand: n = p contiguous)
     a.A = f1; a.B = dlv.ptr[0]; a.C = df2v; a.M = D; a.N = (int)S0; a.K = N;
-    a.lda = N; a.ldb = S0; a.ldc = S0;
+    a.lda = N; a.ldb = (int)S0; a.ldc = (int)S0;
     a.sA = (size_t)D * N; a.sB = (size_t)N * S0; a.sC = (size_t)D * S0;
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((unsigned)((S0 + 63) / 64), (D + 63) / 64, B), dim3(256), 0, s, a);
-    rc = check_launch("gemm_f32_kernel<dF2>");
+    rc = run_gemm<false>(a, B, "gemm_f32_kernel<dF2>", s);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_cols_scatter_back_kernel, dim3(grid_for((size_t)B * D * N, 16384)), dim3(256), 0, s,
                        df2v, df2, B * D, H, W, dlv.g[0]);
