@@ -30,3 +30,12 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from raft_amd import _lib
+    _lib.load()                                   # fail loudly if the extension is missing
+    return torch.device("cuda:0")

@@ -18,14 +18,6 @@ FORK = ["F1_fork_fwd", "F2_fork_bwd", "F3_fork_defaults", "F4_fork_edges"]
 CANON = ["C1_canon_fwd_a", "C1_canon_fwd_b", "C2_canon_bwd"]
 
 
-@pytest.fixture(scope="module")
-def dev():
-    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
-    from raft_amd import _lib
-    _lib.load()                                   # fail loudly if the extension is missing
-    return torch.device("cuda:0")
-
-
 def _t(a, dev, grad=False):
     return torch.from_numpy(np.array(a)).to(dev).requires_grad_(grad)
 
