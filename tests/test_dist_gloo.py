@@ -49,3 +49,20 @@ def test_two_rank_gloo_timing_and_sharding():
     assert (lo0, hi0, lo1, hi1) == (0, 7, 7, 13)
     assert mx0 == mx1 == 2.0          # MAX over ranks, as bench.py reports
     assert d0 == d1 == 13.0           # whole-job units = sum over ranks
+
+
+def test_train_step_harness_two_ranks_gloo():
+    """tools/train_step.py (DDP train-step harness) wired correctly for N > 1: two
+    CPU ranks over gloo with the stock-operator correlation block (the product kernels need a
+    GPU; on the GPU box the same script runs with --corr ours over RCCL)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "train_step.py"),
+           "--device", "cpu", "--corr", "stock", "--steps", "2", "--warmup", "1", "--batch", "1", "--iters", "2",
+           "--size", "128", "160"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
