@@ -141,6 +141,90 @@ def test_full_size_properties(dev):
         assert torch.equal(out[0, :, aa, bb], exp)
 
 
+def test_largest_baseline_shape_1080p(dev):
+    """BASELINE.json configs[4]: 1088x1920 -> 136x240, N = 32640, 5.7 GB pyramid (offsets beyond
+    2**32 bytes).  Too large for the oracle, so checked through a size-independent known answer:
+    at coordinates that are integers at every level (multiples of 8) the canonical lookup returns
+    pooled-volume entries, and pooling the volume over targets == correlating with the avg-pooled
+    fmap2, i.e. out[l, a, b][q] = <f1[:, q], pool_l(f2)[:, y/2^l + b - r, x/2^l + a - r]> / sqrt(D)
+    (0 outside).  fp32 build, bf16 build and the on-the-fly path against that, on sampled queries."""
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    B, D, H, W, L, r = 1, 256, 136, 240, 4, 4
+    g = torch.Generator().manual_seed(1080)
+    f1 = torch.randn(B, D, H, W, generator=g).to(dev)
+    f2 = torch.randn(B, D, H, W, generator=g).to(dev)
+    xs = (torch.randint(-1, W // 8 + 2, (B, H, W), generator=g) * 8).float()
+    ys = (torch.randint(-1, H // 8 + 2, (B, H, W), generator=g) * 8).float()
+    co = torch.stack([xs, ys], 1).to(dev)
+    qs = torch.cat([torch.tensor([0, 1, W - 1, W, H * W - 1, H * W - W]),
+                    torch.randint(0, H * W, (506,), generator=g)]).to(dev)
+
+    exp = torch.zeros(len(qs), L, 2 * r + 1, 2 * r + 1, device=dev)            # [q, l, a, b]
+    f1q = f1.view(D, H * W)[:, qs]                                               # (D, Q)
+    f2l = f2
+    for l in range(L):
+        pad = torch.nn.functional.pad(f2l[0], (r, r, r, r))                      # (D, Hl+2r, Wl+2r)
+        x0 = (co[0, 0].view(-1)[qs] / 2 ** l).long()
+        y0 = (co[0, 1].view(-1)[qs] / 2 ** l).long()
+        Hl, Wl = f2l.shape[-2:]
+        for a in range(2 * r + 1):
+            for b in range(2 * r + 1):
+                xx, yy = x0 + a, y0 + b                                          # padded coordinates
+                ok = (xx >= 0) & (xx < Wl + 2 * r) & (yy >= 0) & (yy < Hl + 2 * r)
+                v = pad[:, yy.clamp(0, Hl + 2 * r - 1), xx.clamp(0, Wl + 2 * r - 1)]     # (D, Q)
+                exp[:, l, a, b] = torch.where(ok, (f1q.double() * v.double()).sum(0) / 16.0, 0.0).float()
+        f2l = torch.nn.functional.avg_pool2d(f2l, 2, stride=2)
+    exp = exp.reshape(len(qs), L * 81).cpu().numpy()
+
+    def sampled(out):
+        return out.view(L * 81, H * W)[:, qs].t().cpu().numpy()
+
+    full = CorrBlock(f1, f2, num_levels=L, radius=r)(co)
+    assert rel_err(sampled(full), exp) <= TOL
+    alt = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)(co)
+    assert rel_err(sampled(alt), exp) <= TOL
+    assert rel_err(alt.cpu().numpy(), full.cpu().numpy()) <= TOL                 # every query, both paths
+    del alt
+    half = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16")(co)
+    assert rel_err(sampled(half), exp) <= 1e-2
+
+
+def test_step_is_hip_graph_capturable(dev):
+    """The entry points launch on the caller's stream, allocate nothing and never synchronise, so
+    a whole step (build + lookups, either path) can be captured into a HIP graph and replayed on
+    new data -- the serving-loop shape.  Replays must reproduce the eager results bit for bit."""
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    B, D, H, W, L, r = 1, 64, 24, 40, 4, 4
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    f1, f2 = mk(B, D, H, W), mk(B, D, H, W)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    base = torch.stack([xx, yy], 0)[None].float().to(dev)
+    cos = [base + mk(B, 2, H, W) * (k + 1) for k in range(3)]
+
+    def step():
+        cb = CorrBlock(f1, f2, num_levels=L, radius=r)
+        alt = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)
+        return [cb(c) for c in cos] + [alt(cos[-1])]
+
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up off the capture
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = step()
+        for trial in range(2):                              # new contents, same buffers
+            f1.copy_(mk(B, D, H, W)); f2.copy_(mk(B, D, H, W))
+            graph.replay()
+            torch.cuda.synchronize()
+            eager = step()
+            for a, b in zip(outs, eager):
+                assert torch.equal(a, b), trial
+
+
 def test_lookup_backward_accumulates_across_iterations(dev):
     """12 lookups, one shared gradient pyramid: equals the oracle's autograd over the same graph."""
     from raft_amd import CorrBlock
