@@ -29,21 +29,50 @@ struct FoldArgs {
 __global__ __launch_bounds__(256)
 void corr_fold_levels_kernel(FoldArgs p)
 {
-    const size_t total = p.BN * (size_t)p.s0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t qb = e / p.s0;
-        const int c = (int)(e - qb * p.s0);
+    // one thread = four consecutive level-0 cells = one 2x2 block of cells, which shares all its
+    // parents (layout.h): a 16-byte load, up to three scalar loads, a 16-byte store
+    const size_t quads = p.BN * (size_t)(p.s0 >> 2);
+    const int qps = (int)(p.s0 >> 2);                       // quads per slab
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < quads; e += (size_t)gridDim.x * 256) {
+        const size_t qb = e / qps;
+        const int c = (int)(e - qb * qps) << 2;
         const int patch = c >> 7, n = (c >> 5) & 3, j = c & 31;
-        float g = p.d0[e];
+        float4 v = *(const float4*)(p.d0 + qb * p.s0 + c);
         // parents in the pooled levels (layout.h): j bits 2,3,4 = dy1, dx1, dx2
         const int dy1 = (j >> 2) & 1, dx1 = (j >> 3) & 1, dx2 = (j >> 4) & 1;
+        float g = 0.f;
         if (p.L > 1) g += 0.25f * p.d1[qb * p.s1 + patch * 32 + n * 8 + (dx1 | (dy1 << 1) | (dx2 << 2))];
         if (p.L > 2) g += 0.0625f * p.d2[qb * p.s2 + patch * 8 + (dx2 | ((n >> 1) << 1) | ((n & 1) << 2))];
         if (p.L > 3) {
             const int ph = patch / p.PW, pwi = patch - ph * p.PW;
             g += 0.015625f * p.d3[qb * p.s3 + ((ph >> 1) * p.PW + pwi) * 4 + (n & 1) + (ph & 1) * 2];
         }
-        p.d0[e] = p.exact ? g * p.scale : g / p.sqrt_d;
+        v.x += g; v.y += g; v.z += g; v.w += g;
+        if (p.exact) { v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale; }
+        else { v.x /= p.sqrt_d; v.y /= p.sqrt_d; v.z /= p.sqrt_d; v.w /= p.sqrt_d; }
+        *(float4*)(p.d0 + qb * p.s0 + c) = v;
+    }
+}
+
+// the same, one cell per thread: for gradient buffers that are not 16-byte aligned
+__global__ __launch_bounds__(256)
+void corr_fold_levels_scalar_kernel(FoldArgs p)
+{
+    const size_t total = p.BN * (size_t)p.s0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t qb = e / p.s0;
+        const int c = (int)(e - qb * p.s0);
+        const int patch = c >> 7, n = (c >> 5) & 3, j = c & 31;
+        const int dy1 = (j >> 2) & 1, dx1 = (j >> 3) & 1, dx2 = (j >> 4) & 1;
+        float g = 0.f;
+        if (p.L > 1) g += 0.25f * p.d1[qb * p.s1 + patch * 32 + n * 8 + (dx1 | (dy1 << 1) | (dx2 << 2))];
+        if (p.L > 2) g += 0.0625f * p.d2[qb * p.s2 + patch * 8 + (dx2 | ((n >> 1) << 1) | ((n & 1) << 2))];
+        if (p.L > 3) {
+            const int ph = patch / p.PW, pwi = patch - ph * p.PW;
+            g += 0.015625f * p.d3[qb * p.s3 + ((ph >> 1) * p.PW + pwi) * 4 + (n & 1) + (ph & 1) * 2];
+        }
+        const float v = p.d0[e] + g;
+        p.d0[e] = p.exact ? v * p.scale : v / p.sqrt_d;
     }
 }
 
@@ -321,7 +350,10 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     f.exact = (mant == 0.5f) && (sq * sq == (float)D);
     f.scale = 1.0f / sq; f.sqrt_d = sq;
     const size_t S0 = (size_t)dlv.g[0].slab;
-    hipLaunchKernelGGL(corr_fold_levels_kernel, dim3(grid_for(BN * S0, 16384)), dim3(256), 0, s, f);
+    if ((uintptr_t)dlv.ptr[0] % 16 == 0)      // slabs are multiples of 128 floats
+        hipLaunchKernelGGL(corr_fold_levels_kernel, dim3(grid_for(BN * S0 / 4, 32768)), dim3(256), 0, s, f);
+    else
+        hipLaunchKernelGGL(corr_fold_levels_scalar_kernel, dim3(grid_for(BN * S0, 16384)), dim3(256), 0, s, f);
     rc = check_launch("corr_fold_levels_kernel");
     if (rc) return rc;
 
