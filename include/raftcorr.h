@@ -74,16 +74,24 @@ int raftcorr_build_pyramid(const float* fmap1, const float* fmap2,
                            float* const* levels, void* workspace, int64_t workspace_bytes,
                            void* stream);
 
-/* Same call with the operands of the contraction rounded to bfloat16 (round-to-nearest-even)
- * and the products accumulated in fp32 on the bf16 matrix cores; the pyramid is fp32 as above.
- * This is the "mixed precision" build (the reference runs its encoders under autocast,
- * core/raft.py:99-103, and the north star's bf16 option): results differ from the fp32 build
- * by the input rounding only (<= 1e-2 relative; typically 2e-3 of max|level0| at D = 256).
- * Same workspace size as raftcorr_build_pyramid. */
-int raftcorr_build_pyramid_bf16(const float* fmap1, const float* fmap2,
+/* Same call with a choice of arithmetic for the contraction (the pyramid is fp32 in every case):
+ *   RAFTCORR_PREC_FP32    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain (= raftcorr_build_pyramid);
+ *   RAFTCORR_PREC_BF16    operands rounded to bfloat16 (RNE), fp32 accumulation on the bf16 matrix
+ *                         cores: the "mixed precision" build (the reference runs its encoders under
+ *                         autocast, core/raft.py:99-103; the north star's bf16 option); differs from
+ *                         fp32 by the input rounding, <= 1e-2 relative (2e-3 of max|level0| at D = 256);
+ *   RAFTCORR_PREC_BF16X3  each operand split into three bfloat16 pieces (24 significand bits) and the
+ *                         six products of weight >= 2^-16 accumulated in fp32: fp32-grade results
+ *                         (error of the order of an fp32 FMA chain's own rounding, far inside the
+ *                         1e-5 parity bar) at bf16 matrix-core speed.
+ * Same workspace size for all. */
+#define RAFTCORR_PREC_FP32   0
+#define RAFTCORR_PREC_BF16   1
+#define RAFTCORR_PREC_BF16X3 2
+int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2,
                                 int B, int D, int H, int W, int num_levels,
                                 float* const* levels, void* workspace, int64_t workspace_bytes,
-                                void* stream);
+                                int precision, void* stream);
 
 /* Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
  * core/utils/utils.py:57-65): for every query q and level l the (2r+1)^2 window of 4-tap

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libraftcorr.so")
 
 MAX_LEVELS = 8
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}          # RAFTCORR_PREC_*
 MODE_FORK = 0
 MODE_CANONICAL = 1
 
@@ -29,8 +30,8 @@ _SIGNATURES = {
     "raftcorr_build_pyramid": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                 ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
                                 ctypes.c_void_p], _c_int),
-    "raftcorr_build_pyramid_bf16": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
+    "raftcorr_build_pyramid_prec": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64, _c_int,
                                      ctypes.c_void_p], _c_int),
     "raftcorr_lookup_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),

@@ -97,17 +97,19 @@ int64_t raftcorr_build_bwd_workspace_bytes(int B, int D, int H, int W)
 
 static int build_pyramid_any(const char* who, const float* fmap1, const float* fmap2, int B, int D, int H, int W,
                              int num_levels, float* const* levels, void* workspace, int64_t workspace_bytes,
-                             bool bf16, void* stream)
+                             int precision, void* stream)
 {
     int rc = check_dims(who, B, H, W);
     if (rc) return rc;
     if (!fmap1 || !fmap2) return fail(RAFTCORR_EINVAL, "%s: null feature map", who);
     if (D < 1) return fail(RAFTCORR_EINVAL, "%s: D = %d", who, D);
+    if (precision != RAFTCORR_PREC_FP32 && precision != RAFTCORR_PREC_BF16 && precision != RAFTCORR_PREC_BF16X3)
+        return fail(RAFTCORR_EINVAL, "%s: precision = %d", who, precision);
     LevelSet lv;
     rc = make_levels(who, levels, H, W, num_levels, lv);
     if (rc) return rc;
     return launch_build_pyramid(fmap1, fmap2, B, D, H, W, num_levels, lv, workspace,
-                                workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, bf16, (hipStream_t)stream);
+                                workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, precision, (hipStream_t)stream);
 }
 
 int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
@@ -115,15 +117,15 @@ int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D,
                            void* stream)
 {
     return build_pyramid_any("build_pyramid", fmap1, fmap2, B, D, H, W, num_levels, levels, workspace,
-                             workspace_bytes, false, stream);
+                             workspace_bytes, RAFTCORR_PREC_FP32, stream);
 }
 
-int raftcorr_build_pyramid_bf16(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
                                 int num_levels, float* const* levels, void* workspace, int64_t workspace_bytes,
-                                void* stream)
+                                int precision, void* stream)
 {
-    return build_pyramid_any("build_pyramid_bf16", fmap1, fmap2, B, D, H, W, num_levels, levels, workspace,
-                             workspace_bytes, true, stream);
+    return build_pyramid_any("build_pyramid_prec", fmap1, fmap2, B, D, H, W, num_levels, levels, workspace,
+                             workspace_bytes, precision, stream);
 }
 
 int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels, int radius,

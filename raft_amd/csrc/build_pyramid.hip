@@ -306,19 +306,25 @@ void corr_build_f32_kernel(BuildArgs p)
 }
 
 // ---------------------------------------------------------------------------------------
-// bf16-operand variant: the same tiling and the same epilogue, operands rounded to bf16 (RNE) by
-// the pack pass, products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA
-// rate), pyramid written in fp32 as before.  The contraction stops being the bottleneck: the
-// kernel runs at the speed of its 1.33 x 4 N^2 bytes of stores.
+// bf16-operand variants: the same tiling and the same epilogue, products on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) accumulated in fp32, pyramid in fp32.
+//   NP = 1  operands rounded to bf16 (RNE): the "mixed precision" build, <= 1e-2 of the fp32 one.
+//   NP = 3  every operand split into three bf16 pieces x = hi + mid + lo (24 significand bits,
+//           each piece with its own exponent) and the six products of weight >= 2^-16 summed:
+//           hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi.  The dropped terms are <= 2^-24
+//           of a product, i.e. fp32 rounding level: the result is as close to the exact dot
+//           product as an fp32 FMA chain is (measured 7e-9 vs 7e-7 of max|C| at D = 256) at 6/16
+//           of its matrix-core time.
+// With either, the contraction stops being the bottleneck: the kernel runs at the speed of its
+// 1.33 x 4 N^2 bytes of stores.
 //
-// Operand panels, per tile:  [k-step (16 k)][h = k half][column 128][8 bf16]   (16 B per lane)
+// Operand panels, per tile:  [k-step (16 k)][piece][h = k half][column 128][8 bf16]  (16 B per lane)
 //   lane (r = l & 31, h = l >> 5) of the MFMA holds A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
 //   A columns = the tile's queries; B columns = n*32 + j  (accumulator n, MFMA column j).
-// A K tile of BK16 = 32 k is 8 KiB per operand, contiguous in the panel: staged exactly like the
-// fp32 kernel's (two 1 KiB DMA pieces per wave and operand).
+// A K tile (2 k-steps for NP = 1, 1 for NP = 3) is contiguous in the panel and staged like the
+// fp32 kernel's, in 1 KiB DMA pieces.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BK16 = 32;
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 {
@@ -329,6 +335,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 }
 
 // grid (tilesM + tilesN, PACK_KSPLIT, B); thread = one column x (Dpad/8/PACK_KSPLIT/2) groups of 8 k
+template <int NP>
 __global__ __launch_bounds__(256)
 void corr_pack_bf16_kernel(PackArgs p)
 {
@@ -353,27 +360,41 @@ void corr_pack_bf16_kernel(PackArgs p)
     }
     const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
     uint4* __restrict__ dst = (uint4*)(second ? p.f2p : p.f1p) +
-                              ((size_t)b * (second ? p.tilesN : p.tilesM) + tile) * (p.Dpad / 8) * 128 + c;
+                              ((size_t)b * (second ? p.tilesN : p.tilesM) + tile) * (p.Dpad / 8) * NP * 128 + c;
     const int groups = p.Dpad / 8, per = groups / PACK_KSPLIT;                // Dpad is a multiple of 64
     for (int g = blockIdx.y * per + gp; g < (blockIdx.y + 1) * per; g += 2) {
-        unsigned short h[8];
+        float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = g * 8 + j;
-            h[j] = f32_to_bf16_rne((t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f);
+            x[j] = (t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f;
         }
-        uint4 w;
-        w.x = h[0] | ((unsigned)h[1] << 16); w.y = h[2] | ((unsigned)h[3] << 16);
-        w.z = h[4] | ((unsigned)h[5] << 16); w.w = h[6] | ((unsigned)h[7] << 16);
-        dst[(size_t)g * 128] = w;                                             // [g = 2*kstep + h][column][8]
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) {
+            unsigned short h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                h[j] = f32_to_bf16_rne(x[j]);
+                x[j] -= __uint_as_float((unsigned)h[j] << 16);                // exact: the next piece's input
+            }
+            uint4 w;
+            w.x = h[0] | ((unsigned)h[1] << 16); w.y = h[2] | ((unsigned)h[3] << 16);
+            w.z = h[4] | ((unsigned)h[5] << 16); w.w = h[6] | ((unsigned)h[7] << 16);
+            dst[(size_t)(((g >> 1) * NP + piece) * 2 + (g & 1)) * 128] = w;   // [k-step][piece][h][column][8]
+        }
     }
 }
 
-template <bool EXACT_MUL>
+template <bool EXACT_MUL, int NP>
 __global__ __launch_bounds__(256, 3)
 void corr_build_bf16_kernel(BuildArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 2048];       // [buf][A|B][8 KiB]
+    // The B tile (one patch of targets) is shared by the four waves and goes through LDS (two
+    // buffers, direct-to-LDS DMA).  A wave's A fragments (its own 32 queries) are private, so they
+    // skip LDS: one coalesced 16-byte global load per lane and fragment, fetched one K tile ahead.
+    constexpr int KS = NP == 1 ? 4 : 2;                 // k-steps per K tile
+    constexpr int OPF = NP * KS * 1024;                 // floats of B per stage (4 KiB per piece and k-step)
+    __shared__ __attribute__((aligned(16))) float smem[2 * OPF];
 
     int b, tm, tn;
     block_to_tile(p, b, tm, tn);
@@ -381,21 +402,26 @@ void corr_build_bf16_kernel(BuildArgs p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int panel = p.Dpad * 64;                                        // floats per panel (Dpad * 128 bf16)
-    const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * panel;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const size_t panel = (size_t)p.Dpad * 64 * NP;                            // floats per panel
     const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * panel;
+    // this lane's slot in every A fragment: ((k-step * NP + piece) * 2 + kh) * 128 + row
+    const float4* __restrict__ pa = (const float4*)(p.f1p + ((size_t)b * p.tilesM + tm) * panel) +
+                                    kh * 128 + wave * 32 + l31;
 
-    auto stage = [&](int kt, int buf) {
-        float* la = smem + buf * 4096;
-        float* lb = la + 2048;
-        const float* ga = pa + (size_t)kt * 2048;
-        const float* gb = pb + (size_t)kt * 2048;
+    auto stage_b = [&](int kt, int buf) {
+        float* lb = smem + buf * OPF;
+        const float* gb = pb + (size_t)kt * OPF;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wave * 2 + i;
-            glds16(ga + piece * 256 + lane * 4, la + piece * 256);
+        for (int i = 0; i < NP * KS; ++i) {
+            const int piece = wave * NP * KS + i;                              // 1 KiB DMA pieces
             glds16(gb + piece * 256 + lane * 4, lb + piece * 256);
         }
+    };
+    float4 a_nxt[KS * NP], a_cur[KS * NP];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < KS * NP; ++i) a_nxt[i] = pa[(size_t)(kt * KS * NP + i) * 256];
     };
 
     f32x16 acc[4];
@@ -404,24 +430,34 @@ void corr_build_bf16_kernel(BuildArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-    const int nk = p.Dpad / BK16;
-    const int kh = lane >> 5, l31 = lane & 31;
-    stage(0, 0);
+    const int nk = p.Dpad / (16 * KS);
+    stage_b(0, 0);
+    load_a(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        // fragment of k-step s: 16-byte slot ((2s + kh) * 128 + column)
-        const bf16x8* la = (const bf16x8*)(smem + buf * 4096) + kh * 128 + wave * 32 + l31;
-        const bf16x8* lb = (const bf16x8*)(smem + buf * 4096 + 2048) + kh * 128 + l31;
 #pragma unroll
-        for (int s = 0; s < BK16 / 16; ++s) {
-            const bf16x8 a = la[s * 256];
-            const bf16x8 b0 = lb[s * 256], b1 = lb[s * 256 + 32], b2 = lb[s * 256 + 64], b3 = lb[s * 256 + 96];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3, acc[3], 0, 0, 0);
+        for (int i = 0; i < KS * NP; ++i) a_cur[i] = a_nxt[i];
+        if (kt + 1 < nk) { stage_b(kt + 1, buf ^ 1); load_a(kt + 1); }
+        // B fragment (k-step s, piece c): 16-byte slot (((s * NP + c) * 2 + kh) * 128 + column)
+        const bf16x8* lb = (const bf16x8*)(smem + buf * OPF) + kh * 128 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 a[NP];
+#pragma unroll
+            for (int c = 0; c < NP; ++c) a[c] = __builtin_bit_cast(bf16x8, a_cur[s * NP + c]);
+            // piece of B outermost, small products first: lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi
+#pragma unroll
+            for (int cb = NP - 1; cb >= 0; --cb) {
+                bf16x8 bb[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bb[n] = lb[(s * NP + cb) * 256 + n * 32];
+#pragma unroll
+                for (int ca = NP - 1 - cb; ca >= 0; --ca)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ca], bb[n], acc[n], 0, 0, 0);
+            }
         }
     }
     build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
@@ -450,12 +486,14 @@ size_t build_workspace_bytes(int B, int D, int H, int W)
     const int N = H * W;
     const size_t Dpad = (size_t)(D + 63) / 64 * 64;
     const size_t tilesM = (N + BM - 1) / BM, tilesN = (size_t)patches_h(H) * patches_w(W);
-    return (size_t)B * Dpad * 128 * (tilesM + tilesN) * sizeof(float);
+    return (size_t)B * Dpad * 128 * (tilesM + tilesN) * 6;      // fp32: 4 B, bf16: 2 B, 3 x bf16: 6 B per element
 }
 
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, void* workspace, size_t workspace_bytes, bool bf16, hipStream_t s)
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s)
 {
+    const bool bf16 = precision != RAFTCORR_PREC_FP32;
+    const int np = precision == RAFTCORR_PREC_BF16X3 ? 3 : 1;
     if (workspace_bytes < build_workspace_bytes(B, D, H, W) || !workspace)
         return fail(RAFTCORR_EINVAL, "build_pyramid: workspace too small (%zu < %zu bytes)",
                     workspace_bytes, build_workspace_bytes(B, D, H, W));
@@ -472,11 +510,12 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     if (const char* e = getenv("RC_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : GROUP_M;   // lab knob
     a.nblk_per_b = a.tilesM * a.tilesN;
     float* f1p = (float*)workspace;
-    float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * (bf16 ? 64 : 128);
+    float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * (bf16 ? 64 * np : 128);
     int rc;
     if (bf16) {
         PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN};
-        hipLaunchKernelGGL(corr_pack_bf16_kernel, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
+        if (np == 3) hipLaunchKernelGGL(corr_pack_bf16_kernel<3>, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
+        else         hipLaunchKernelGGL(corr_pack_bf16_kernel<1>, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
         rc = check_launch("corr_pack_bf16_kernel");
     } else {
         rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
@@ -498,8 +537,13 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     if (nblk > 0x7fffffffLL) return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: grid too large");
     dim3 grid((unsigned)nblk), block(256);
     if (bf16) {
-        if (exact) hipLaunchKernelGGL(corr_build_bf16_kernel<true>, grid, block, 0, s, a);
-        else       hipLaunchKernelGGL(corr_build_bf16_kernel<false>, grid, block, 0, s, a);
+        if (np == 3) {
+            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 3>), grid, block, 0, s, a);
+            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 3>), grid, block, 0, s, a);
+        } else {
+            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 1>), grid, block, 0, s, a);
+            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 1>), grid, block, 0, s, a);
+        }
     } else {
         if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);
         else       hipLaunchKernelGGL((corr_build_f32_kernel<false, BK, WPS>), grid, block, 0, s, a);

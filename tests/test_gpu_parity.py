@@ -187,6 +187,9 @@ def test_largest_baseline_shape_1080p(dev):
     del alt
     half = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16")(co)
     assert rel_err(sampled(half), exp) <= 1e-2
+    del half
+    split = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16x3")(co)
+    assert rel_err(sampled(split), exp) <= TOL
 
 
 def test_step_is_hip_graph_capturable(dev):
@@ -296,6 +299,16 @@ def test_bf16_build_option(shape, dev):
         assert rel_err(got, exact.corr_pyramid[l].numpy()) <= 1e-2
     assert rel_err(out, rounded(co).numpy()) <= TOL
     assert rel_err(out, exact(co).numpy()) <= 1e-2
+    # precision="bf16x3": three bf16 pieces per operand, six products -- fp32-grade: judged against
+    # the float64 oracle, it must be as close as the fp32 build is (both far inside the 1e-5 bar)
+    exact64 = O.build_pyramid_direct(f1.numpy(), f2.numpy(), L)
+    cb3 = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r, precision="bf16x3")
+    cb1 = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r)
+    for l in range(L):
+        e3 = rel_err(cb3.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
+        e1 = rel_err(cb1.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
+        assert e3 <= 1e-6 and e3 <= 2 * e1 + 1e-7, (l, e3, e1)
+    assert rel_err(cb3(co.to(dev)).cpu().numpy(), exact(co).numpy()) <= TOL
 
 
 # ---------------------------------------------------------------------------------------
