@@ -101,14 +101,15 @@ def extras(f1, f2, coords, dev):
     bf, bb, _ = algorithmic_work()
     out = {}
     with torch.no_grad():
-        for prec, terms, note in (("bf16x3", 6, "fp32-grade: 3 bf16 pieces per operand, 6 products (parity <= 1e-5)"),
+        for prec, terms, note in (("fp16x2", 3, "fp32-grade: maps range-scaled, 2 fp16 pieces per operand, 3 products (parity <= 1e-5)"),
+                                  ("bf16x3", 6, "fp32-grade: 3 bf16 pieces per operand, 6 products (parity <= 1e-5)"),
                                   ("bf16", 1, "operands rounded to bf16 (parity <= 1e-2)")):
             t = ev_time_us(lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec))
-            out["build_" + prec] = {"kernel": f"corr_build_bf16_kernel<{3 if terms == 6 else 1}> (+ pack)",
+            out["build_" + prec] = {"kernel": "corr_build_bf16_kernel (+ pack" + (" + max|x| pass)" if terms == 3 else ")"),
                                     "us_per_launch": t, "bound": "hbm", "achieved": bb / t / 1e3,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bb / t / 1e3 / HBM_PEAK_GBS,
                                     "algorithmic_bytes": bb, "algorithmic_TFLOPs": bf / t / 1e6,
-                                    "executed_bf16_TFLOPs": terms * bf / t / 1e6, "note": note}
+                                    "executed_16bit_TFLOPs": terms * bf / t / 1e6, "note": note}
         alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
         alt_flops = 2.0 * B * N * LEVELS * T * T * D
         alt_bytes = 4.0 * (B * N * D + sum(B * (H >> l) * (W >> l) * D for l in range(LEVELS)) + 2 * B * N +

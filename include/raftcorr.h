@@ -83,11 +83,18 @@ int raftcorr_build_pyramid(const float* fmap1, const float* fmap2,
  *   RAFTCORR_PREC_BF16X3  each operand split into three bfloat16 pieces (24 significand bits) and the
  *                         six products of weight >= 2^-16 accumulated in fp32: fp32-grade results
  *                         (error of the order of an fp32 FMA chain's own rounding, far inside the
- *                         1e-5 parity bar) at bf16 matrix-core speed.
+ *                         1e-5 parity bar) at bf16 matrix-core speed; any finite fp32 inputs;
+ *   RAFTCORR_PREC_FP16X2  each map scaled by a power of two into the top of fp16's range (one extra
+ *                         max|x| pass), each operand split into two fp16 pieces (22 significand
+ *                         bits), three products (hi*hi + hi*lo + lo*hi) accumulated in fp32 and
+ *                         unscaled exactly: also fp32-grade (2e-7 of max|level0| at D = 256, the
+ *                         fp32 FMA chain itself is at 7e-7) at half the matrix-core work of BF16X3.
+ *                         Elements more than ~2^22 below their map's max lose low-order bits.
  * Same workspace size for all. */
 #define RAFTCORR_PREC_FP32   0
 #define RAFTCORR_PREC_BF16   1
 #define RAFTCORR_PREC_BF16X3 2
+#define RAFTCORR_PREC_FP16X2 3
 int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2,
                                 int B, int D, int H, int W, int num_levels,
                                 float* const* levels, void* workspace, int64_t workspace_bytes,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libraftcorr.so")
 
 MAX_LEVELS = 8
-PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}          # RAFTCORR_PREC_*
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 3}          # RAFTCORR_PREC_*
 MODE_FORK = 0
 MODE_CANONICAL = 1
 

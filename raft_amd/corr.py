@@ -220,7 +220,9 @@ class CorrBlock:
     pyramid, the lookup and the backward pass are fp32 in every case:
       "fp32"    (default) exact fp32 FMA chain on the fp32 matrix cores;
       "bf16x3"  operands split into three bfloat16 pieces, six bf16 MFMA products: fp32-grade
-                results (inside the 1e-5 parity bar by orders of magnitude), ~3x faster build;
+                results (inside the 1e-5 parity bar by orders of magnitude), faster build;
+      "fp16x2"  maps scaled by a power of two, operands split into two fp16 pieces, three fp16
+                MFMA products: fp32-grade too, the fastest of the accurate builds;
       "bf16"    operands rounded to bfloat16: differs by the input rounding, <= 1e-2."""
 
     def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32"):

@@ -103,7 +103,7 @@ static int build_pyramid_any(const char* who, const float* fmap1, const float* f
     if (rc) return rc;
     if (!fmap1 || !fmap2) return fail(RAFTCORR_EINVAL, "%s: null feature map", who);
     if (D < 1) return fail(RAFTCORR_EINVAL, "%s: D = %d", who, D);
-    if (precision != RAFTCORR_PREC_FP32 && precision != RAFTCORR_PREC_BF16 && precision != RAFTCORR_PREC_BF16X3)
+    if (precision < RAFTCORR_PREC_FP32 || precision > RAFTCORR_PREC_FP16X2)
         return fail(RAFTCORR_EINVAL, "%s: precision = %d", who, precision);
     LevelSet lv;
     rc = make_levels(who, levels, H, W, num_levels, lv);

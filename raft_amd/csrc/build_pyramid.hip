@@ -25,6 +25,7 @@
 //           two, so the values equal avg_pool2d's up to the order of the three additions.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace raftcorr {
 
@@ -49,6 +50,7 @@ constexpr int PACK_KSPLIT = 8;
 struct PackArgs {
     const float* f1; const float* f2; float* f1p; float* f2p;
     int D, Dpad, H, W, tilesM, tilesN;
+    const float* maxpart;       // fp16 pieces only: MAXPARTS partial maxima of |fmap1|, then of |fmap2| (device memory)
 };
 
 __global__ __launch_bounds__(256)
@@ -88,7 +90,7 @@ void corr_pack_kernel(PackArgs p)
 int launch_pack_operands(const float* f1, const float* f2, float* f1p, float* f2p, int B, int D, int Dpad,
                          int H, int W, int tilesM, int tilesN, hipStream_t s)
 {
-    PackArgs a{f1, f2, f1p, f2p, D, Dpad, H, W, tilesM, tilesN};
+    PackArgs a{f1, f2, f1p, f2p, D, Dpad, H, W, tilesM, tilesN, nullptr};
     hipLaunchKernelGGL(corr_pack_kernel, dim3(tilesM + tilesN, PACK_KSPLIT, B), dim3(256), 0, s, a);
     return check_launch("corr_pack_kernel");
 }
@@ -106,7 +108,30 @@ struct BuildArgs {
     int group_m;          // query tiles walked together (L2 reuse of the operand panels)
     float inv_sqrt_d;     // used when sqrt(D) is a power of two (exact)
     float sqrt_d;         // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
+    const float* maxpart;     // fp16 pieces only (else null): the operands were scaled, see range_exponent()
 };
+
+constexpr int MAXPARTS = 128;    // partial maxima per feature map (one per block of corr_maxabs_kernel)
+
+// every lane gets the maximum of a map's partial maxima (no LDS, no barrier: each wave for itself)
+__device__ __forceinline__ float wave_max_of_partials(const float* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    float m = fmaxf(part[lane], part[lane + 64]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+// fp16 pieces: power-of-two factor that maps max|x| into [2^14, 2^15) -- the top of fp16's range, so
+// that the low-order pieces stay normal numbers.  1 for an all-zero or non-finite map.
+__device__ __forceinline__ int range_exponent(float m)
+{
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+    return 15 - e;
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v)
@@ -154,6 +179,10 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
                                                int wave, int lane)
 {
     const int kh = lane >> 5, l31 = lane & 31;
+    float unscale = 1.0f;                                      // exact power of two
+    if (p.maxpart)
+        unscale = ldexpf(1.0f, -(range_exponent(wave_max_of_partials(p.maxpart)) +
+                                 range_exponent(wave_max_of_partials(p.maxpart + MAXPARTS))));
     // ---- epilogue ------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Stores go through buffer descriptors that cover exactly this wave's valid query rows:
@@ -193,7 +222,7 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
         float v[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            v[n] = EXACT_MUL ? acc[n][reg] * p.inv_sqrt_d : acc[n][reg] / p.sqrt_d;
+            v[n] = EXACT_MUL ? acc[n][reg] * (p.inv_sqrt_d * unscale) : (acc[n][reg] * unscale) / p.sqrt_d;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[n]), r0, row * s0b + c0 + n * 128, 0, 0);
         }
         if (L > 1) {
@@ -325,6 +354,28 @@ void corr_build_f32_kernel(BuildArgs p)
 // fp32 kernel's, in 1 KiB DMA pieces.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// partial maxima of |x| of both feature maps: grid (MAXPARTS, 2), out[map * MAXPARTS + block]
+__global__ __launch_bounds__(256)
+void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ f2, size_t n, float* __restrict__ out)
+{
+    __shared__ float red[4];
+    const float* __restrict__ x = blockIdx.y ? f2 : f1;
+    float m = 0.f;
+    const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;           // 16-byte loads when aligned
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)MAXPARTS * 256) {
+        const float4 v = ((const float4*)x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)MAXPARTS * 256)
+        m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.y * MAXPARTS + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 {
@@ -335,7 +386,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 }
 
 // grid (tilesM + tilesN, PACK_KSPLIT, B); thread = one column x (Dpad/8/PACK_KSPLIT/2) groups of 8 k
-template <int NP>
+template <int NP, bool F16>
 __global__ __launch_bounds__(256)
 void corr_pack_bf16_kernel(PackArgs p)
 {
@@ -362,20 +413,28 @@ void corr_pack_bf16_kernel(PackArgs p)
     uint4* __restrict__ dst = (uint4*)(second ? p.f2p : p.f1p) +
                               ((size_t)b * (second ? p.tilesN : p.tilesM) + tile) * (p.Dpad / 8) * NP * 128 + c;
     const int groups = p.Dpad / 8, per = groups / PACK_KSPLIT;                // Dpad is a multiple of 64
+    float rscale = 1.0f;
+    if (F16) rscale = ldexpf(1.0f, range_exponent(wave_max_of_partials(p.maxpart + (second ? MAXPARTS : 0))));
     for (int g = blockIdx.y * per + gp; g < (blockIdx.y + 1) * per; g += 2) {
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = g * 8 + j;
-            x[j] = (t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f;
+            x[j] = (t >= 0 && k < p.D) ? src[(size_t)k * N] * rscale : 0.f;
         }
 #pragma unroll
         for (int piece = 0; piece < NP; ++piece) {
             unsigned short h[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                h[j] = f32_to_bf16_rne(x[j]);
-                x[j] -= __uint_as_float((unsigned)h[j] << 16);                // exact: the next piece's input
+                if (F16) {
+                    const _Float16 hv = (_Float16)x[j];                       // RNE
+                    h[j] = __builtin_bit_cast(unsigned short, hv);
+                    x[j] -= (float)hv;                                        // exact: the next piece's input
+                } else {
+                    h[j] = f32_to_bf16_rne(x[j]);
+                    x[j] -= __uint_as_float((unsigned)h[j] << 16);
+                }
             }
             uint4 w;
             w.x = h[0] | ((unsigned)h[1] << 16); w.y = h[2] | ((unsigned)h[3] << 16);
@@ -385,7 +444,7 @@ void corr_pack_bf16_kernel(PackArgs p)
     }
 }
 
-template <bool EXACT_MUL, int NP>
+template <bool EXACT_MUL, int NP, bool F16>
 __global__ __launch_bounds__(256, 3)
 void corr_build_bf16_kernel(BuildArgs p)
 {
@@ -393,6 +452,7 @@ void corr_build_bf16_kernel(BuildArgs p)
     // buffers, direct-to-LDS DMA).  A wave's A fragments (its own 32 queries) are private, so they
     // skip LDS: one coalesced 16-byte global load per lane and fragment, fetched one K tile ahead.
     constexpr int KS = NP == 1 ? 4 : 2;                 // k-steps per K tile
+    static_assert(NP <= 3, "pieces");
     constexpr int OPF = NP * KS * 1024;                 // floats of B per stage (4 KiB per piece and k-step)
     __shared__ __attribute__((aligned(16))) float smem[2 * OPF];
 
@@ -438,28 +498,50 @@ void corr_build_bf16_kernel(BuildArgs p)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KS * NP; ++i) a_cur[i] = a_nxt[i];
+#if defined(RC_LAB_NO_BSTAGE) || defined(RC_LAB_NO_ALOAD)   // tools/build_lab.hip only: ablations
+        if (kt + 1 < nk) {
+#if !defined(RC_LAB_NO_BSTAGE)
+            stage_b(kt + 1, buf ^ 1);
+#endif
+#if !defined(RC_LAB_NO_ALOAD)
+            load_a(kt + 1);
+#endif
+        }
+#else
         if (kt + 1 < nk) { stage_b(kt + 1, buf ^ 1); load_a(kt + 1); }
+#endif
         // B fragment (k-step s, piece c): 16-byte slot (((s * NP + c) * 2 + kh) * 128 + column)
-        const bf16x8* lb = (const bf16x8*)(smem + buf * OPF) + kh * 128 + l31;
+        const float4* lb = (const float4*)(smem + buf * OPF) + kh * 128 + l31;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            bf16x8 a[NP];
+            float4 a[NP];
 #pragma unroll
-            for (int c = 0; c < NP; ++c) a[c] = __builtin_bit_cast(bf16x8, a_cur[s * NP + c]);
+            for (int c = 0; c < NP; ++c) a[c] = a_cur[s * NP + c];
             // piece of B outermost, small products first: lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi
 #pragma unroll
             for (int cb = NP - 1; cb >= 0; --cb) {
-                bf16x8 bb[4];
+                float4 bb[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) bb[n] = lb[(s * NP + cb) * 256 + n * 32];
 #pragma unroll
                 for (int ca = NP - 1 - cb; ca >= 0; --ca)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ca], bb[n], acc[n], 0, 0, 0);
+                    for (int n = 0; n < 4; ++n) {
+                        if (F16) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, a[ca]), __builtin_bit_cast(f16x8, bb[n]), acc[n], 0, 0, 0);
+                        else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[ca]), __builtin_bit_cast(bf16x8, bb[n]), acc[n], 0, 0, 0);
+                    }
             }
         }
     }
+#if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
+    return;
+#endif
     build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
 }
 
@@ -486,14 +568,16 @@ size_t build_workspace_bytes(int B, int D, int H, int W)
     const int N = H * W;
     const size_t Dpad = (size_t)(D + 63) / 64 * 64;
     const size_t tilesM = (N + BM - 1) / BM, tilesN = (size_t)patches_h(H) * patches_w(W);
-    return (size_t)B * Dpad * 128 * (tilesM + tilesN) * 6;      // fp32: 4 B, bf16: 2 B, 3 x bf16: 6 B per element
+    // operand panels (fp32: 4 B, bf16: 2 B, 2 x fp16: 4 B, 3 x bf16: 6 B per element) + partial maxima
+    return (size_t)B * Dpad * 128 * (tilesM + tilesN) * 6 + 2 * MAXPARTS * sizeof(float);
 }
 
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
                          const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s)
 {
-    const bool bf16 = precision != RAFTCORR_PREC_FP32;
-    const int np = precision == RAFTCORR_PREC_BF16X3 ? 3 : 1;
+    const bool bf16 = precision != RAFTCORR_PREC_FP32;          // 16-bit pieces on the bf16/fp16 matrix cores
+    const bool f16 = precision == RAFTCORR_PREC_FP16X2;
+    const int np = precision == RAFTCORR_PREC_BF16X3 ? 3 : f16 ? 2 : 1;
     if (workspace_bytes < build_workspace_bytes(B, D, H, W) || !workspace)
         return fail(RAFTCORR_EINVAL, "build_pyramid: workspace too small (%zu < %zu bytes)",
                     workspace_bytes, build_workspace_bytes(B, D, H, W));
@@ -512,10 +596,19 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     float* f1p = (float*)workspace;
     float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * (bf16 ? 64 * np : 128);
     int rc;
+    a.maxpart = nullptr;
     if (bf16) {
-        PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN};
-        if (np == 3) hipLaunchKernelGGL(corr_pack_bf16_kernel<3>, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
-        else         hipLaunchKernelGGL(corr_pack_bf16_kernel<1>, dim3(a.tilesM + a.tilesN, PACK_KSPLIT, B), dim3(256), 0, s, pk);
+        PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN, nullptr};
+        const dim3 pgrid(a.tilesM + a.tilesN, PACK_KSPLIT, B);
+        if (f16) {          // range pass: max|x| of both maps -> power-of-two scales (pack) and the unscale (epilogue)
+            float* mp = (float*)((char*)workspace + build_workspace_bytes(B, D, H, W) - 2 * MAXPARTS * sizeof(float));
+            hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, (size_t)B * D * a.N, mp);
+            rc = check_launch("corr_maxabs_kernel");
+            if (rc) return rc;
+            pk.maxpart = mp; a.maxpart = mp;
+            hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, dim3(256), 0, s, pk);
+        } else if (np == 3) hipLaunchKernelGGL((corr_pack_bf16_kernel<3, false>), pgrid, dim3(256), 0, s, pk);
+        else                hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, dim3(256), 0, s, pk);
         rc = check_launch("corr_pack_bf16_kernel");
     } else {
         rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
@@ -537,12 +630,15 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     if (nblk > 0x7fffffffLL) return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: grid too large");
     dim3 grid((unsigned)nblk), block(256);
     if (bf16) {
-        if (np == 3) {
-            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 3>), grid, block, 0, s, a);
-            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 3>), grid, block, 0, s, a);
+        if (f16) {
+            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 2, true>), grid, block, 0, s, a);
+            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 2, true>), grid, block, 0, s, a);
+        } else if (np == 3) {
+            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 3, false>), grid, block, 0, s, a);
+            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 3, false>), grid, block, 0, s, a);
         } else {
-            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 1>), grid, block, 0, s, a);
-            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 1>), grid, block, 0, s, a);
+            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 1, false>), grid, block, 0, s, a);
+            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 1, false>), grid, block, 0, s, a);
         }
     } else {
         if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);

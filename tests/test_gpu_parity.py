@@ -190,6 +190,9 @@ def test_largest_baseline_shape_1080p(dev):
     del half
     split = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16x3")(co)
     assert rel_err(sampled(split), exp) <= TOL
+    del split
+    split = CorrBlock(f1, f2, num_levels=L, radius=r, precision="fp16x2")(co)
+    assert rel_err(sampled(split), exp) <= TOL
 
 
 def test_step_is_hip_graph_capturable(dev):
@@ -302,13 +305,22 @@ def test_bf16_build_option(shape, dev):
     # precision="bf16x3": three bf16 pieces per operand, six products -- fp32-grade: judged against
     # the float64 oracle, it must be as close as the fp32 build is (both far inside the 1e-5 bar)
     exact64 = O.build_pyramid_direct(f1.numpy(), f2.numpy(), L)
-    cb3 = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r, precision="bf16x3")
     cb1 = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r)
+    for prec in ("bf16x3", "fp16x2"):
+        cb3 = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r, precision=prec)
+        for l in range(L):
+            e3 = rel_err(cb3.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
+            e1 = rel_err(cb1.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
+            assert e3 <= 1e-6 and e3 <= 2 * e1 + 2e-7, (prec, l, e3, e1)
+        assert rel_err(cb3(co.to(dev)).cpu().numpy(), exact(co).numpy()) <= TOL
+    # fp16x2 rescales each map by a power of two: maps of very different magnitude must work
+    big, small = f1 * 3.0e4, f2 * 2.0e-5
+    cbs = CorrBlock(big.to(dev), small.to(dev), num_levels=L, radius=r, precision="fp16x2")
+    ref = O.CorrBlockOracle(big, small, L, r)
     for l in range(L):
-        e3 = rel_err(cb3.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
-        e1 = rel_err(cb1.corr_pyramid[l].cpu().numpy().reshape(exact64[l].shape), exact64[l])
-        assert e3 <= 1e-6 and e3 <= 2 * e1 + 1e-7, (l, e3, e1)
-    assert rel_err(cb3(co.to(dev)).cpu().numpy(), exact(co).numpy()) <= TOL
+        assert rel_err(cbs.corr_pyramid[l].cpu().numpy(), ref.corr_pyramid[l].numpy()) <= TOL
+    zero = CorrBlock(torch.zeros_like(f1).to(dev), f2.to(dev), num_levels=L, radius=r, precision="fp16x2")
+    assert not zero.corr_pyramid[0].any().item()
 
 
 # ---------------------------------------------------------------------------------------

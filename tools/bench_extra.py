@@ -63,6 +63,7 @@ for tag, (Hs, Ws) in {"sintel": (55, 128), "1080p": (136, 240)}.items():
         res[f"{tag}_build_fp32_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4), reps=10)
         res[f"{tag}_build_bf16_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4, precision="bf16"), reps=10)
         res[f"{tag}_build_bf16x3_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4, precision="bf16x3"), reps=10)
+        res[f"{tag}_build_fp16x2_us"] = ev_time(lambda: CorrBlock(a, bb, 4, 4, precision="fp16x2"), reps=10)
         cbx = CorrBlock(a, bb, 4, 4)
         cox = coords_for(1, Hs, Ws, 3.0, g)
         res[f"{tag}_lookup_us"] = ev_time(lambda: cbx(cox))

@@ -42,17 +42,31 @@ int main(int argc, char** argv)
     CK(hipMemcpy(f1, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(f2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&ws, build_workspace_bytes(B, D, H, W)));
-    float* f1p = ws; float* f2p = ws + (size_t)B * a.tilesM * D * 128;
-    a.f1p = f1p; a.f2p = f2p; a.Dpad = D;
-    launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
+    a.PW = patches_w(W); a.group_m = GROUP_M; a.Dpad = D;
     dim3 grid(a.nblk_per_b), block(256);
     const double flops = 2.0 * N * (double)N * D;
-#define RUN(name, ...) { float us = timeit([&]() { hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, 0, a); }); printf("%-40s %8.1f us  %6.1f TF\n", name, us, flops / us * 1e-6); }
-    RUN("BK=32, 2 waves/SIMD (product)", corr_build_f32_kernel<true, 32, 2>);
-    RUN("BK=16, 2 waves/SIMD", corr_build_f32_kernel<true, 16, 2>);
-    RUN("BK=16, 4 waves/SIMD", corr_build_f32_kernel<true, 16, 4>);
-    RUN("BK=16, 3 waves/SIMD", corr_build_f32_kernel<true, 16, 3>);
-    RUN("BK=8, 4 waves/SIMD", corr_build_f32_kernel<true, 8, 4>);
-    printf("pack: %.1f us\n", timeit([&]() { launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0); }));
+#define RUN(name, ...) { float us = timeit([&]() { hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, 0, a); }); printf("%-40s %8.1f us  %6.1f TF (algorithmic)\n", name, us, flops / us * 1e-6); }
+    {   // fp32 operands
+        float* f1p = ws; float* f2p = ws + (size_t)B * a.tilesM * D * 128;
+        a.f1p = f1p; a.f2p = f2p;
+        launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
+        RUN("fp32 BK=16, 3 waves/SIMD (product)", corr_build_f32_kernel<true, 16, 3>);
+        printf("pack fp32: %.1f us\n", timeit([&]() { launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0); }));
+    }
+    PackArgs pk{f1, f2, ws, nullptr, D, D, H, W, a.tilesM, a.tilesN, nullptr};
+    a.maxpart = nullptr;
+    dim3 pgrid(a.tilesM + a.tilesN, PACK_KSPLIT, B);
+    {   // bf16 operands
+        pk.f2p = ws + (size_t)B * a.tilesM * D * 64; a.f1p = pk.f1p; a.f2p = pk.f2p;
+        hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, block, 0, 0, pk);
+        RUN("bf16 (1 piece)", corr_build_bf16_kernel<true, 1, false>);
+        printf("pack bf16: %.1f us\n", timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, block, 0, 0, pk); }));
+    }
+    {   // 3 x bf16 operands
+        pk.f2p = ws + (size_t)B * a.tilesM * D * 64 * 3; a.f1p = pk.f1p; a.f2p = pk.f2p;
+        hipLaunchKernelGGL((corr_pack_bf16_kernel<3, false>), pgrid, block, 0, 0, pk);
+        RUN("bf16x3 (3 pieces, 6 products)", corr_build_bf16_kernel<true, 3, false>);
+        printf("pack bf16x3: %.1f us\n", timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<3, false>), pgrid, block, 0, 0, pk); }));
+    }
     return 0;
 }
