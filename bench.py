@@ -119,6 +119,17 @@ def extras(f1, f2, coords, dev):
             out[tag] = {"kernel": "alt_tile_fwd_kernel", "us_per_launch": t,
                         "algorithmic_TFLOPs": alt_flops / t / 1e6, "compulsory_GBs": alt_bytes / t / 1e3,
                         "note": "identity flow" if tag.endswith("0") else "flow = 8 steps of N(0, 3^2) drift per pixel"}
+        # the whole step again with the fp32-grade split build (CorrBlock(..., precision="fp16x2")): same
+        # workload and parity bar as the headline number, which stays on the plain fp32 MFMA build
+        def split_pair():
+            cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="fp16x2")
+            for c in coords:
+                cb(c)
+        n = 100
+        t = ev_time_us(split_pair, reps=n, warm=10)
+        out["step_fp16x2"] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_step": t / 1e3, "steps": n,
+                              "note": "build with 2 fp16 pieces x 3 products (parity <= 1e-5, measured 2e-7), "
+                                      f"then the same {ITERS} lookups"}
         big = torch.empty(1 << 28, dtype=torch.float32, device=dev)        # 1 GiB
         big2 = torch.empty_like(big)
         out["hbm_achievable_GBs"] = {"fill": big.numel() * 4 / ev_time_us(lambda: big.zero_(), 5) / 1e3,
