@@ -490,7 +490,11 @@ void corr_build_bf16_kernel(BuildArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
+#if defined(RC_LAB_SKIP_MAINLOOP)      // tools/build_lab.hip only: time the epilogue alone
+    const int nk = 1;
+#else
     const int nk = p.Dpad / (16 * KS);
+#endif
     stage_b(0, 0);
     load_a(0);
     for (int kt = 0; kt < nk; ++kt) {
