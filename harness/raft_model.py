@@ -85,7 +85,10 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+        # `corr` is the (B, 324, H, W) lookup result, or -- when the correlation block fuses convc1
+        # into its lookup (RAFT(..., fuse_convc1=True)) -- already relu(convc1(lookup))
+        c1 = corr if corr.shape[1] == self.convc1.out_channels else F.relu(self.convc1(corr))
+        cor = F.relu(self.convc2(c1))
         flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
         return torch.cat([F.relu(self.conv(torch.cat([cor, flo], 1))), flow], 1)
 
@@ -167,9 +170,13 @@ class InputPadder:
 
 
 class RAFT(nn.Module):
-    def __init__(self, corr_factory):
+    def __init__(self, corr_factory, fuse_convc1=False):
+        """fuse_convc1: inference only; the correlation block must offer lookup_conv1x1
+        (raft_amd.CorrBlock does): the motion encoder's first 1x1 conv + ReLU then runs inside
+        the lookup kernel and the (B, 324, H, W) tensor is never materialised."""
         super().__init__()
         self.corr_factory = corr_factory
+        self.fuse_convc1 = fuse_convc1
         self.fnet = BasicEncoder(256, "instance")
         self.cnet = BasicEncoder(HIDDEN + CONTEXT, "batch")
         self.update_block = BasicUpdateBlock()
@@ -192,7 +199,11 @@ class RAFT(nn.Module):
         preds = []
         for _ in range(iters):
             coords1 = coords1.detach()
-            corr = corr_fn(coords1)
+            if self.fuse_convc1 and not torch.is_grad_enabled():
+                enc = self.update_block.encoder.convc1
+                corr = corr_fn.lookup_conv1x1(coords1, enc.weight, enc.bias, relu=True)
+            else:
+                corr = corr_fn(coords1)
             net, mask, delta = self.update_block(net, inp, corr, coords1 - coords0)
             coords1 = coords1 + delta
             preds.append(convex_upsample(coords1 - coords0, mask))

@@ -109,6 +109,22 @@ int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2,
 int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels,
                         int radius, const float* coords, int mode, float* out, void* stream);
 
+/* Lookup fused with its consumer in RAFT's update block, the motion encoder's 1x1 convolution
+ * `convc1` + bias + ReLU (core/update.py:83,90: cor = F.relu(self.convc1(corr))):
+ *   out[b, c, q] = act( sum_k weight[c, k] * lookup(coords)[b, k, q] + bias[c] ),  k = l*rd*rd + a*rd + b
+ * canonical coordinates (RAFTCORR_MODE_CANONICAL), num_levels <= 4, radius 3 or 4.  The
+ * (B, L*rd*rd, H, W) lookup result is never written to memory; the product runs on the fp32
+ * matrix cores (exact fp32 FMA chain).  Forward only (inference).
+ * The weight is packed once per model with raftcorr_conv1x1_pack_weight (weight: (Cout, Cin) row-major
+ * = the conv's (Cout, Cin, 1, 1) tensor; packed: raftcorr_conv1x1_packed_bytes(Cout, Cin) bytes of
+ * device memory).  bias: (Cout) or NULL.  relu: 0/1.  out: (B, Cout, H, W), overwritten. */
+int64_t raftcorr_conv1x1_packed_bytes(int Cout, int Cin);
+int raftcorr_conv1x1_pack_weight(const float* weight, int Cout, int Cin, float* packed,
+                                 int64_t packed_bytes, void* stream);
+int raftcorr_lookup_conv1x1_fwd(const float* const* levels, int B, int H, int W, int num_levels,
+                                int radius, const float* coords, const float* packed_weight,
+                                const float* bias, int Cout, int relu, float* out, void* stream);
+
 /* Backward of raftcorr_lookup_fwd (replaces grid_sampler_2d_backward reached through
  * core/utils/utils.py:65).  dlevels[l] (same layout as levels, float32) is ACCUMULATED into
  * (+=): zero it once, then call this for every lookup of the frame pair; no dense per-call

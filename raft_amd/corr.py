@@ -282,6 +282,38 @@ class CorrBlock:
             torch.zeros(1, dtype=torch.float32, device=coords.device)
         return _Lookup.apply(anchor, coords, p, self.radius, mode)
 
+    def lookup_conv1x1(self, coords, weight, bias=None, relu=True):
+        """Canonical lookup fused with a 1x1 convolution (+ bias, + ReLU) over its channels: what
+        RAFT's motion encoder does first with the result, `F.relu(self.convc1(corr))`
+        (core/update.py:83,90).  coords (B, 2, H, W); weight (Cout, L*rd*rd[, 1, 1]); returns
+        (B, Cout, H, W) without materialising the (B, L*rd*rd, H, W) tensor.  Inference only: no
+        autograd graph is recorded.  The packed weight is cached per weight tensor version."""
+        p = self._pyr
+        _require_cuda(coords=coords, weight=weight)
+        if tuple(coords.shape) != (p.B, 2, p.H, p.W):
+            raise RuntimeError(f"CorrBlock: coords must be ({p.B}, 2, {p.H}, {p.W}); got {tuple(coords.shape)}")
+        cin = self.num_levels * (2 * self.radius + 1) ** 2
+        if weight.dim() == 4 and weight.shape[2:] == (1, 1):
+            weight = weight[:, :, 0, 0]
+        if weight.dim() != 2 or weight.shape[1] != cin:
+            raise RuntimeError(f"CorrBlock: weight must be (Cout, {cin}[, 1, 1]); got {tuple(weight.shape)}")
+        if self.num_levels > 4 or self.radius not in (3, 4):
+            raise RuntimeError("CorrBlock.lookup_conv1x1 supports num_levels <= 4 and radius 3 or 4")
+        cout = weight.shape[0]
+        if bias is not None and tuple(bias.shape) != (cout,):
+            raise RuntimeError(f"CorrBlock: bias must be ({cout},)")
+        lib = _lib.load()
+        packed = _packed_conv_weight(lib, weight.detach(), cout, cin)
+        coords = _f32c(coords.detach())
+        b32 = _f32c(bias.detach()) if bias is not None else None
+        out = torch.empty(p.B, cout, p.H, p.W, dtype=torch.float32, device=coords.device)
+        with _guard(coords):
+            _lib.check(lib.raftcorr_lookup_conv1x1_fwd(p.ptrs, p.B, p.H, p.W, p.L, self.radius, coords.data_ptr(),
+                                                       packed.data_ptr(), b32.data_ptr() if b32 is not None else None,
+                                                       cout, 1 if relu else 0, out.data_ptr(), _stream(coords)),
+                       "lookup_conv1x1_fwd")
+        return out
+
     @staticmethod
     def corr(fmap1, fmap2):
         """core/corr.py:53-61: (B, D, H, W) x2 -> (B, H, W, 1, H, W), already divided by sqrt(D)."""
@@ -305,6 +337,26 @@ def bilinear_sampler(img, coords, mode='bilinear', mask=False):
         m = (xgrid > -1) & (ygrid > -1) & (xgrid < 1) & (ygrid < 1)
         return img, m.float()
     return img
+
+
+_PACKED_WEIGHTS = {}          # (data_ptr, version, shape, device) -> packed weight; one entry per live weight
+
+
+def _packed_conv_weight(lib, weight, cout, cin):
+    key = (weight.data_ptr(), weight._version, cout, cin, weight.device)
+    hit = _PACKED_WEIGHTS.get(weight.data_ptr())
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = _f32c(weight)
+    nbytes = lib.raftcorr_conv1x1_packed_bytes(cout, cin)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    with _guard(w):
+        _lib.check(lib.raftcorr_conv1x1_pack_weight(w.data_ptr(), cout, cin, packed.data_ptr(), nbytes, _stream(w)),
+                   "conv1x1_pack_weight")
+    if len(_PACKED_WEIGHTS) > 64:
+        _PACKED_WEIGHTS.clear()
+    _PACKED_WEIGHTS[weight.data_ptr()] = (key, packed)
+    return packed
 
 
 class _AltLookup(torch.autograd.Function):

@@ -143,6 +143,37 @@ int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num
     return launch_lookup_fwd(lv, B, H, W, num_levels, radius, coords, mode, out, (hipStream_t)stream);
 }
 
+int64_t raftcorr_conv1x1_packed_bytes(int Cout, int Cin)
+{
+    if (Cout < 1 || Cin < 1) return 0;
+    return (int64_t)conv1x1_packed_bytes(Cout, Cin);
+}
+
+int raftcorr_conv1x1_pack_weight(const float* weight, int Cout, int Cin, float* packed, int64_t packed_bytes,
+                                 void* stream)
+{
+    if (!weight || !packed) return fail(RAFTCORR_EINVAL, "conv1x1_pack_weight: null pointer");
+    if (Cout < 1 || Cin < 1) return fail(RAFTCORR_EINVAL, "conv1x1_pack_weight: Cout=%d Cin=%d", Cout, Cin);
+    if (packed_bytes < (int64_t)conv1x1_packed_bytes(Cout, Cin))
+        return fail(RAFTCORR_EINVAL, "conv1x1_pack_weight: packed buffer too small");
+    return launch_conv1x1_pack_weight(weight, Cout, Cin, packed, (hipStream_t)stream);
+}
+
+int raftcorr_lookup_conv1x1_fwd(const float* const* levels, int B, int H, int W, int num_levels, int radius,
+                                const float* coords, const float* packed_weight, const float* bias, int Cout,
+                                int relu, float* out, void* stream)
+{
+    int rc = check_dims("lookup_conv1x1_fwd", B, H, W);
+    if (rc) return rc;
+    if (!coords || !out || !packed_weight) return fail(RAFTCORR_EINVAL, "lookup_conv1x1_fwd: null pointer");
+    if (radius < 0 || Cout < 1) return fail(RAFTCORR_EINVAL, "lookup_conv1x1_fwd: radius=%d Cout=%d", radius, Cout);
+    LevelSet lv;
+    rc = make_levels("lookup_conv1x1_fwd", levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_lookup_conv1x1(lv, B, H, W, num_levels, radius, coords, packed_weight, bias, Cout, relu, out,
+                                 (hipStream_t)stream);
+}
+
 int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels, int B, int H, int W,
                         int num_levels, int radius, const float* coords, int mode, const float* dout,
                         float* dcoords, void* stream)

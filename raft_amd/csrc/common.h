@@ -26,6 +26,10 @@ int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, con
 int launch_lookup_bwd(const LevelSet& lv, const LevelSet& dlv, bool have_dlevels, int B, int H, int W,
                       int L, int r, const float* coords, int mode, const float* dout,
                       float* dcoords, hipStream_t s);
+size_t conv1x1_packed_bytes(int Cout, int Cin);
+int launch_conv1x1_pack_weight(const float* w, int Cout, int Cin, float* packed, hipStream_t s);
+int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
+                          const float* wpacked, const float* bias, int Cout, int relu, float* out, hipStream_t s);
 int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
                      const LevelSet& dlv, float* df1, float* df2, void* workspace, size_t workspace_bytes,
                      hipStream_t s);

@@ -28,6 +28,7 @@
 // filter of dOut, added to d(level) with a plain read-modify-write: a (query, tap) cell
 // belongs to exactly one thread of one block, so no atomics are needed.
 #include "common.h"
+#include <algorithm>
 
 #ifndef RC_STAMP            // tools/lookup_lab2.hip defines it for diagnostic (timing-stamp) builds
 #define RC_STAMP(i)
@@ -195,8 +196,13 @@ __device__ __forceinline__ size_t fwd4_smem_floats()
     return (size_t)QB * G::STQ + 2 * QB * G::NB + 5 * QB;
 }
 
+// xsink == nullptr: results go to p.out.  Otherwise (fused consumer, canonical mode) the block's
+// results are left in LDS as xsink[(l * rd2 + channel) * XS + query] for a GEMM that follows.
+constexpr int XS = QB + 1;
+
 template <int R, int KIND>
-__device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem)
+__device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem, int l, int b, int q0, int tid,
+                                                  float* xsink = nullptr)
 {
     typedef BlockGeom<R> G;
     float* tile = smem;                                  // [QB][STQ]
@@ -208,9 +214,6 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
     int* ymask = xmask + QB;                             // validity bits of the TW tile rows
     int* spar = ymask + QB;                              // px | py << 1
 
-    const int l = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB;
-    const int tid = threadIdx.x;
     const LevelGeom g = p.lv.g[l];
     const int N = p.N;
     const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
@@ -337,7 +340,8 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
             const int ch = tid / QB + i * 8;
-            if (vq && ch < rd2) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
+            if (xsink) { if (ch < rd2) xsink[(l * rd2 + ch) * XS + qi] = vq ? o[i] : 0.f; }
+            else if (vq && ch < rd2) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
         }
     }
     RC_STAMP(3);
@@ -465,10 +469,10 @@ void corr_lookup_fwd_kernel(LookupArgs p)
         if (threadIdx.x < QB) ((int*)(smem + QB * BlockGeom<R>::STQ + 2 * QB * BlockGeom<R>::NB))[4 * QB + threadIdx.x] = 0;  // spar
         __syncthreads();
         switch (kind) {
-        case 0: lookup_fwd_blocks<R, 0>(p, smem); return;
-        case 1: lookup_fwd_blocks<R, 1>(p, smem); return;
-        case 2: lookup_fwd_blocks<R, 2>(p, smem); return;
-        case 3: lookup_fwd_blocks<R, 3>(p, smem); return;
+        case 0: lookup_fwd_blocks<R, 0>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 1: lookup_fwd_blocks<R, 1>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 2: lookup_fwd_blocks<R, 2>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 3: lookup_fwd_blocks<R, 3>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
         default: lookup_fwd_body<R, 4>(p, smem); return;
         }
     } else {
@@ -626,6 +630,154 @@ void corr_lookup_dcoords_kernel(LookupArgs p)
             c[0] = gx; c[N] = gy;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lookup fused with its only consumer in RAFT: the motion encoder's 1x1 convolution
+// convc1 (L*(2r+1)^2 -> Cout) + bias + ReLU (core/update.py:83,90).  The (B, L*rd2, H, W) lookup
+// result is never written: a 1024-thread block runs the four levels' lookups side by side (one
+// 256-thread group per level, same code as the stand-alone kernel), leaves the 32 x Cin result tile
+// in LDS and multiplies it with the weight on the fp32 matrix cores:
+//   out[c][q] = relu( sum_k Wt[c][k] * X[k][q] + bias[c] ),  MFMA 32x32x2: rows = 32 channels,
+//   columns = the block's 32 queries; wave w < Cout/32 owns channel tile w.
+// The weight is pre-packed once (raftcorr_conv1x1_pack_weight) into MFMA-fragment order so that
+// every A fragment is one coalesced dword load per lane.
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* wpacked;   // [Cout/32 tiles][ceil(Cin/2) k-steps][64 lanes]
+    const float* bias;      // [Cout] or null
+    float* out;             // (B, Cout, N)
+    int Cin, Cout, relu;
+};
+
+typedef float f32x16l __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256)
+void conv1x1_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin)
+{
+    const int ksteps = (Cin + 1) / 2, tiles = (Cout + 31) / 32;
+    const size_t total = (size_t)tiles * ksteps * 64;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const size_t ts = e >> 6;
+        const int s = (int)(ts % ksteps), mt = (int)(ts / ksteps);
+        const int c = mt * 32 + (lane & 31), k = 2 * s + (lane >> 5);
+        packed[e] = (c < Cout && k < Cin) ? w[(size_t)c * Cin + k] : 0.f;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(1024)
+void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef BlockGeom<R> G;
+    constexpr int GF = QB * G::STQ + 2 * QB * G::NB + 5 * QB;       // floats per level group
+    constexpr int GFA = (GF + 3) & ~3;
+    float* X = smem + 4 * GFA;                                       // [Cin (+1)][XS]
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int b = blockIdx.z, q0 = blockIdx.x * QB;
+    float* gs = smem + grp * GFA;
+    if (tid < QB) ((int*)(gs + QB * G::STQ + 2 * QB * G::NB))[4 * QB + tid] = 0;     // spar
+    if (threadIdx.x < XS) X[cv.Cin * XS + threadIdx.x] = 0.f;       // zero row for an odd Cin's last k-step
+    __syncthreads();
+    if (grp < p.L) {
+        switch (grp) {                                               // level l < 4 has layout kind l
+        case 0: lookup_fwd_blocks<R, 0>(p, gs, 0, b, q0, tid, X); break;
+        case 1: lookup_fwd_blocks<R, 1>(p, gs, 1, b, q0, tid, X); break;
+        case 2: lookup_fwd_blocks<R, 2>(p, gs, 2, b, q0, tid, X); break;
+        default: lookup_fwd_blocks<R, 3>(p, gs, 3, b, q0, tid, X); break;
+        }
+    } else {
+        __syncthreads();                                             // the two barriers of lookup_fwd_blocks
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // GEMM: (channel tile, K split) pairs over the 16 waves; partial products meet in LDS (the level
+    // groups' tiles are free now), then every thread finishes a few outputs: bias, ReLU, coalesced store
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int tiles = (cv.Cout + 31) / 32, ksteps = (cv.Cin + 1) / 2;
+    const int nsplit = max(1, min(16 / tiles, (4 * GFA) / (tiles * 32 * XS)));   // partial slabs must fit
+    const int kper = (ksteps + nsplit - 1) / nsplit;
+    float* red = smem;                                               // [nsplit][tiles * 32][XS] partial sums
+    constexpr int PB = 16;                                           // weight fragments per batch, two batches in flight
+    for (int pr = wave; pr < tiles * nsplit; pr += 16) {
+        const int mt = pr % tiles, sp = pr / tiles;
+        const int s0 = sp * kper, s1 = min(ksteps, s0 + kper);
+        const float* __restrict__ wp = cv.wpacked + (size_t)mt * ksteps * 64 + lane;
+        const float* xb = X + kh * XS + l31;
+        f32x16l acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float a_cur[PB], a_nxt[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) a_cur[u] = wp[(size_t)min(s0 + u, ksteps - 1) * 64];
+        for (int s = s0; s < s1; s += PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) a_nxt[u] = wp[(size_t)min(s + PB + u, ksteps - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (s + u < s1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u], xb[2 * (s + u) * XS], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < PB; ++u) a_cur[u] = a_nxt[u];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            red[((sp * tiles + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh) * XS + l31] = acc[i];
+    }
+    __syncthreads();
+    {
+        const int qi = threadIdx.x & 31, q = q0 + qi;
+        if (q < p.N)
+            for (int c = threadIdx.x >> 5; c < cv.Cout; c += 32) {
+                float v = cv.bias ? cv.bias[c] : 0.f;
+                for (int sp = 0; sp < nsplit; ++sp) v += red[(sp * tiles * 32 + c) * XS + qi];   // fixed order
+                if (cv.relu) v = fmaxf(v, 0.f);
+                cv.out[((size_t)b * cv.Cout + c) * p.N + q] = v;
+            }
+    }
+}
+
+size_t conv1x1_packed_bytes(int Cout, int Cin)
+{
+    return sizeof(float) * (size_t)((Cout + 31) / 32) * ((Cin + 1) / 2) * 64;
+}
+
+int launch_conv1x1_pack_weight(const float* w, int Cout, int Cin, float* packed, hipStream_t s)
+{
+    const size_t total = conv1x1_packed_bytes(Cout, Cin) / sizeof(float);
+    hipLaunchKernelGGL(conv1x1_pack_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256),
+                       0, s, w, packed, Cout, Cin);
+    return check_launch("conv1x1_pack_weight_kernel");
+}
+
+int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
+                          const float* wpacked, const float* bias, int Cout, int relu, float* out, hipStream_t s)
+{
+    if (L > 4) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: more than 4 levels");
+    if (r != 4 && r != 3) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: radius %d (3 and 4 are built)", r);
+    if (Cout > 384) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: Cout = %d > 384", Cout);
+    LookupArgs a = {};
+    a.lv = lv; a.coords = coords; a.out = nullptr;
+    a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = RAFTCORR_MODE_CANONICAL;
+    const int rd = 2 * r + 1;
+    ConvArgs c = {wpacked, bias, out, L * rd * rd, Cout, relu};
+    const int T = 2 * r + 2, NB = T / 2 + 1, TW = 2 * NB;
+    const size_t gf = ((size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 5 * QB + 3) & ~(size_t)3;
+    const size_t sm = sizeof(float) * (4 * gf + (size_t)(c.Cin + 1) * XS);
+    if (sm > 160 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: needs %zu bytes of LDS", sm);
+    dim3 grid((a.N + QB - 1) / QB, 1, B), block(1024);
+    hipError_t e;
+    if (r == 4) {
+        e = hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e == hipSuccess) hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<4>, grid, block, sm, s, a, c);
+    } else {
+        e = hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e == hipSuccess) hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<3>, grid, block, sm, s, a, c);
+    }
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "lookup_conv1x1: %s", hipGetErrorString(e));
+    return check_launch("corr_lookup_conv1x1_kernel");
 }
 
 static size_t lookup_smem(int r, bool bwd)

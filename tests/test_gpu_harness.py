@@ -13,9 +13,9 @@ from harness.raft_model import RAFT, InputPadder, sequence_loss, synthetic_pair
 pytestmark = pytest.mark.gpu
 
 
-def _flows(dev, factory, iters, size=(200, 320), seed=0):
+def _flows(dev, factory, iters, size=(200, 320), seed=0, fuse=False):
     torch.manual_seed(0)
-    model = RAFT(factory).to(dev).eval()
+    model = RAFT(factory, fuse_convc1=fuse).to(dev).eval()
     i1, i2, _ = synthetic_pair(1, *size, seed=seed, device=dev)
     pad = InputPadder(i1.shape)
     a, b = pad.pad(i1, i2)
@@ -43,6 +43,15 @@ def test_flow_matches_reference_corr_over_32_iterations(which, dev, reference_fl
           (lambda a, b: AlternateCorrBlock(a, b, num_levels=4, radius=4))
     ours = _flows(dev, fac, 32)
     assert np.isfinite(ours[-1]).all() and np.abs(reference_flows[-1]).max() > 1.0    # the loop moved
+    for it in (11, 31):
+        assert _epe(ours[it], reference_flows[it]) <= 0.01, f"iteration {it + 1}"
+
+
+def test_flow_with_fused_convc1_and_split_precision_build(dev, reference_flows):
+    """The fast inference configuration: fp16x2 build + lookup fused with convc1 -- still within the
+    north star's 0.01 px of the reference CorrBlock after 12 and 32 iterations."""
+    from raft_amd import CorrBlock
+    ours = _flows(dev, lambda a, b: CorrBlock(a, b, num_levels=4, radius=4, precision="fp16x2"), 32, fuse=True)
     for it in (11, 31):
         assert _epe(ours[it], reference_flows[it]) <= 0.01, f"iteration {it + 1}"
 

@@ -323,6 +323,33 @@ def test_bf16_build_option(shape, dev):
     assert not zero.corr_pyramid[0].any().item()
 
 
+@pytest.mark.parametrize("case", [(1, 64, 24, 40, 4, 4, 256, True), (2, 32, 17, 22, 3, 3, 96, True),
+                                  (1, 16, 13, 19, 2, 4, 40, False)])
+def test_lookup_fused_with_convc1(case, dev):
+    """CorrBlock.lookup_conv1x1 == relu(conv1x1(oracle lookup)) (core/update.py:83,90 on the
+    reference's CorrBlock output): ragged query blocks, odd and even Cin, Cout not a multiple of 32,
+    with and without bias / ReLU, out-of-map windows."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    B, D, H, W, L, r, cout, relu = case
+    rs = np.random.RandomState(sum(case[:7]))
+    f1 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    f2 = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32))
+    co = torch.from_numpy((rs.rand(B, 2, H, W) * [[[W + 6]], [[H + 6]]] - 3).astype(np.float32))
+    cin = L * (2 * r + 1) ** 2
+    wt = torch.from_numpy((rs.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32))
+    bias = torch.from_numpy(rs.randn(cout).astype(np.float32)) if relu else None
+    ref = torch.nn.functional.conv2d(O.CorrBlockOracle(f1, f2, L, r)(co).double(), wt.double(),
+                                     None if bias is None else bias.double())
+    ref = (torch.relu(ref) if relu else ref).numpy()
+    cb = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=r)
+    got = cb.lookup_conv1x1(co.to(dev), wt.to(dev), None if bias is None else bias.to(dev), relu=relu)
+    assert got.shape == ref.shape
+    assert rel_err(got.cpu().numpy(), ref) <= TOL
+    again = cb.lookup_conv1x1(co.to(dev), wt.to(dev), None if bias is None else bias.to(dev), relu=relu)
+    assert torch.equal(got, again)
+
+
 # ---------------------------------------------------------------------------------------
 # on-the-fly ("alternate") path
 # ---------------------------------------------------------------------------------------

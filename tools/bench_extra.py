@@ -77,6 +77,15 @@ res["hbm_fill_GBs"] = big.numel() * 4 / ev_time(lambda: big.zero_(), reps=5) / 1
 res["hbm_copy_GBs"] = 2 * big.numel() * 4 / ev_time(lambda: big2.copy_(big), reps=5) / 1e3
 res["hbm_read_GBs"] = big.numel() * 4 / ev_time(lambda: big.sum(), reps=5) / 1e3
 del big, big2
+# lookup fused with convc1 (324 -> 256, bias, ReLU) vs lookup + stock conv2d, Sintel shape
+a = torch.randn(1, 256, 55, 128, generator=g).to(dev); bb = torch.randn(1, 256, 55, 128, generator=g).to(dev)
+wt = (torch.randn(256, 324, 1, 1, generator=g) / 18).to(dev); bs = torch.randn(256, generator=g).to(dev)
+cox = coords_for(1, 55, 128, 3.0, g)
+with torch.no_grad():
+    cbx = CorrBlock(a, bb, 4, 4)
+    res["sintel_lookup_plus_conv2d_us"] = ev_time(lambda: torch.relu(torch.nn.functional.conv2d(cbx(cox), wt, bs)))
+    res["sintel_lookup_conv1x1_fused_us"] = ev_time(lambda: cbx.lookup_conv1x1(cox, wt, bs))
+    del cbx
 # config 4: FlyingThings crops B=6, 12 lookups fwd + bwd
 B, D, H, W = 6, 256, 50, 90
 f1 = torch.randn(B, D, H, W, generator=g).to(dev).requires_grad_(True)

@@ -27,6 +27,8 @@ factories = {
     "stock_ops_gpu": lambda x, y: StockCorrBlock(x, y, 4, 4),
     "all_pairs_fp32": lambda x, y: CorrBlock(x, y, num_levels=4, radius=4),
     "all_pairs_bf16": lambda x, y: CorrBlock(x, y, num_levels=4, radius=4, precision="bf16"),
+    "all_pairs_fp16x2": lambda x, y: CorrBlock(x, y, num_levels=4, radius=4, precision="fp16x2"),
+    "all_pairs_fp16x2_fused_convc1": lambda x, y: CorrBlock(x, y, num_levels=4, radius=4, precision="fp16x2"),
     "on_the_fly": lambda x, y: AlternateCorrBlock(x, y, num_levels=4, radius=4),
 }
 
@@ -47,7 +49,15 @@ class Timed:
 
     def __call__(self, x, y):
         blk = self._span(lambda: self.factory(x, y))
-        return lambda c: self._span(lambda: blk(c))
+        timed = self
+
+        class _Blk:
+            def __call__(self, c):
+                return timed._span(lambda: blk(c))
+
+            def lookup_conv1x1(self, *a, **k):
+                return timed._span(lambda: blk.lookup_conv1x1(*a, **k))
+        return _Blk()
 
     def total_ms(self):
         torch.cuda.synchronize()
@@ -60,7 +70,7 @@ res, flows = {"iters": iters, "image": "436x1024 (padded 440x1024)", "weights": 
 for name, fac in factories.items():
     torch.manual_seed(0)
     timed = Timed(fac)
-    model = RAFT(timed).to(dev).eval()
+    model = RAFT(timed, fuse_convc1=name.endswith("fused_convc1")).to(dev).eval()
     with torch.no_grad():
         for _ in range(3):
             model(a, b, iters=iters, test_mode=True)
