@@ -250,6 +250,7 @@ class CorrBlock:
             self._anchor = None
         self._flat = flat            # packed levels (autograd-tracked when the features are)
         self._logical = None
+        self._packed = None          # lookup_conv1x1: (key, packed weight, weight)
 
     @property
     def corr_pyramid(self):
@@ -287,7 +288,7 @@ class CorrBlock:
         RAFT's motion encoder does first with the result, `F.relu(self.convc1(corr))`
         (core/update.py:83,90).  coords (B, 2, H, W); weight (Cout, L*rd*rd[, 1, 1]); returns
         (B, Cout, H, W) without materialising the (B, L*rd*rd, H, W) tensor.  Inference only: no
-        autograd graph is recorded.  The packed weight is cached per weight tensor version."""
+        autograd graph is recorded.  The packed weight is cached on this CorrBlock per weight tensor version."""
         p = self._pyr
         _require_cuda(coords=coords, weight=weight)
         if tuple(coords.shape) != (p.B, 2, p.H, p.W):
@@ -303,7 +304,12 @@ class CorrBlock:
         if bias is not None and tuple(bias.shape) != (cout,):
             raise RuntimeError(f"CorrBlock: bias must be ({cout},)")
         lib = _lib.load()
-        packed = _packed_conv_weight(lib, weight.detach(), cout, cin)
+        # packed once per CorrBlock (i.e. per frame pair: 3 us) and weight version; the cache holds the
+        # weight tensor itself, so its address cannot be reused by another tensor meanwhile
+        key = (weight.data_ptr(), weight._version)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, _pack_conv_weight(lib, weight.detach(), cout, cin), weight)
+        packed = self._packed[1]
         coords = _f32c(coords.detach())
         b32 = _f32c(bias.detach()) if bias is not None else None
         out = torch.empty(p.B, cout, p.H, p.W, dtype=torch.float32, device=coords.device)
@@ -339,23 +345,13 @@ def bilinear_sampler(img, coords, mode='bilinear', mask=False):
     return img
 
 
-_PACKED_WEIGHTS = {}          # (data_ptr, version, shape, device) -> packed weight; one entry per live weight
-
-
-def _packed_conv_weight(lib, weight, cout, cin):
-    key = (weight.data_ptr(), weight._version, cout, cin, weight.device)
-    hit = _PACKED_WEIGHTS.get(weight.data_ptr())
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def _pack_conv_weight(lib, weight, cout, cin):
     w = _f32c(weight)
     nbytes = lib.raftcorr_conv1x1_packed_bytes(cout, cin)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
     with _guard(w):
         _lib.check(lib.raftcorr_conv1x1_pack_weight(w.data_ptr(), cout, cin, packed.data_ptr(), nbytes, _stream(w)),
                    "conv1x1_pack_weight")
-    if len(_PACKED_WEIGHTS) > 64:
-        _PACKED_WEIGHTS.clear()
-    _PACKED_WEIGHTS[weight.data_ptr()] = (key, packed)
     return packed
 
 

@@ -768,13 +768,22 @@ int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r,
     const size_t sm = sizeof(float) * (4 * gf + (size_t)(c.Cin + 1) * XS);
     if (sm > 160 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: needs %zu bytes of LDS", sm);
     dim3 grid((a.N + QB - 1) / QB, 1, B), block(1024);
-    hipError_t e;
-    if (r == 4) {
-        e = hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e == hipSuccess) hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<4>, grid, block, sm, s, a, c);
-    } else {
-        e = hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e == hipSuccess) hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<3>, grid, block, sm, s, a, c);
+    // more than 64 KiB of dynamic LDS needs opting in, once per kernel and device context
+    static thread_local int allowed_tab[64][2] = {};            // per device (the attribute is per device)
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    int* allowed = allowed_tab[devid & 63];
+    const int which = r == 4 ? 0 : 1;
+    if (e == hipSuccess && allowed[which] < (int)sm) {
+        e = r == 4 ? hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<4>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                   : hipFuncSetAttribute((const void*)corr_lookup_conv1x1_kernel<3>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) allowed[which] = 160 * 1024;
+    }
+    if (e == hipSuccess) {
+        if (r == 4) hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<4>, grid, block, sm, s, a, c);
+        else        hipLaunchKernelGGL(corr_lookup_conv1x1_kernel<3>, grid, block, sm, s, a, c);
     }
     if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "lookup_conv1x1: %s", hipGetErrorString(e));
     return check_launch("corr_lookup_conv1x1_kernel");
