@@ -172,6 +172,10 @@ __device__ __forceinline__ void block_to_tile(const BuildArgs& p, int& b, int& t
     tn = within / gsz;
 }
 
+#ifndef RC_EPI_AUX
+#define RC_EPI_AUX 0        // cache-policy bits of the epilogue's buffer stores (lab knob)
+#endif
+
 // Shared by the fp32 and bf16 kernels (both MFMAs have the same 32x32 C/D map): scale, store
 // level 0, pool levels 1..3 out of the accumulators.
 template <bool EXACT_MUL>
@@ -223,7 +227,7 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             v[n] = EXACT_MUL ? acc[n][reg] * (p.inv_sqrt_d * unscale) : (acc[n][reg] * unscale) / p.sqrt_d;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[n]), r0, row * s0b + c0 + n * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[n]), r0, row * s0b + c0 + n * 128, 0, RC_EPI_AUX);
         }
         if (L > 1) {
             float t1[4];
@@ -234,7 +238,7 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
             }
             const float lo1 = (quad & 1) ? t1[1] : t1[0], hi1 = (quad & 1) ? t1[3] : t1[2];
             const float mine1 = (quad & 2) ? hi1 : lo1;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine1 * 0.25f), r1, row * s1b + c1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine1 * 0.25f), r1, row * s1b + c1, 0, RC_EPI_AUX);
             if (L > 2) {
                 float t2[4];
 #pragma unroll
@@ -244,12 +248,12 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
                 }
                 const float lo2 = (l15 & 1) ? t2[1] : t2[0], hi2 = (l15 & 1) ? t2[3] : t2[2];
                 const float mine2 = (l15 & 2) ? hi2 : lo2;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine2 * 0.0625f), r2, row * s2b + c2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine2 * 0.0625f), r2, row * s2b + c2, 0, RC_EPI_AUX);
                 if (L > 3) {
                     const float u0 = t2[0] + t2[2], u1 = t2[1] + t2[3];      // upper + lower tile
                     const float mine = (lane & 1) ? u1 : u0;
                     const float other = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mine), 0x401F));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((mine + other) * 0.015625f), r3, row * s3b + c3, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((mine + other) * 0.015625f), r3, row * s3b + c3, 0, RC_EPI_AUX);
                 }
             }
         }
@@ -444,8 +448,12 @@ void corr_pack_bf16_kernel(PackArgs p)
     }
 }
 
+#ifndef RC_BF16_WAVES
+#define RC_BF16_WAVES 3     // waves per SIMD the 16-bit kernels' registers are bounded for (lab knob)
+#endif
+
 template <bool EXACT_MUL, int NP, bool F16>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, RC_BF16_WAVES)
 void corr_build_bf16_kernel(BuildArgs p)
 {
     // The B tile (one patch of targets) is shared by the four waves and goes through LDS (two

@@ -68,5 +68,16 @@ int main(int argc, char** argv)
         RUN("bf16x3 (3 pieces, 6 products)", corr_build_bf16_kernel<true, 3, false>);
         printf("pack bf16x3: %.1f us\n", timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<3, false>), pgrid, block, 0, 0, pk); }));
     }
+    {   // 2 x fp16 operands (range scaling skipped: inputs are in [-1, 1]; maxpart = null -> unscale 1)
+        pk.f2p = ws + (size_t)B * a.tilesM * D * 64 * 2; a.f1p = pk.f1p; a.f2p = pk.f2p;
+        float* mp; CK(hipMalloc(&mp, 2 * MAXPARTS * 4));
+        hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp);
+        pk.maxpart = mp; a.maxpart = mp;
+        hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk);
+        RUN("fp16x2 (2 pieces, 3 products)", corr_build_bf16_kernel<true, 2, true>);
+        printf("pack fp16x2: %.1f us, max|x| pass: %.1f us\n",
+               timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk); }),
+               timeit([&]() { hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp); }));
+    }
     return 0;
 }
