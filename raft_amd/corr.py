@@ -241,6 +241,9 @@ class CorrBlock:
             raise RuntimeError("CorrBlock: radius must be >= 0")
         fmap1, fmap2 = _f32c(fmap1), _f32c(fmap2)
         B, D, H, W = fmap1.shape
+        if (H >> (num_levels - 1)) < 1 or (W >> (num_levels - 1)) < 1:
+            # the reference fails in F.avg_pool2d ("Output size is too small"), core/corr.py:26
+            raise RuntimeError(f"CorrBlock: a {H} x {W} map has no level {num_levels - 1}: output size is too small")
         self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device)
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
             flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr, precision)

@@ -38,8 +38,9 @@ static int make_levels(const char* who, const float* const* ptrs, int H, int W, 
         else { lv.g[l].h = lv.g[l].hp = H >> l; lv.g[l].w = lv.g[l].wp = W >> l; lv.g[l].pw = 0; lv.g[l].kind = 4;
                lv.g[l].slab = (int64_t)(H >> l) * (W >> l); }
         lv.ptr[l] = const_cast<float*>(ptrs[l]);
-        if (!ptrs[l] && lv.g[l].h > 0 && lv.g[l].w > 0)
-            return fail(RAFTCORR_EINVAL, "%s: level %d pointer is null", who, l);
+        if (lv.g[l].h < 1 || lv.g[l].w < 1)      // the reference's avg_pool2d raises "Output size is too small" here
+            return fail(RAFTCORR_EINVAL, "%s: level %d of a %d x %d map is empty", who, l, H, W);
+        if (!ptrs[l]) return fail(RAFTCORR_EINVAL, "%s: level %d pointer is null", who, l);
     }
     return RAFTCORR_OK;
 }

@@ -71,6 +71,9 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.raftcorr_build_pyramid(8, 8, 1, 256, 55, 128, 9, ptrs, None, 0, None) == -1
     assert lib.raftcorr_build_workspace_bytes(1, 256, 55, 128) == 6 * 256 * 128 * (55 + 56) + 1024
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, -1, 8, 0, 8, None) == -1
+    some = (ctypes.c_void_p * 4)(8, 8, 8, 8)
+    assert lib.raftcorr_lookup_fwd(some, 1, 6, 8, 4, 4, 8, 0, 8, None) == -1        # level 3 of a 6x8 map is empty
+    assert b"empty" in lib.raftcorr_last_error()
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, 4, 8, 7, 8, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 0, 4, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 16, 8, None) == -2   # radius > 7
