@@ -76,6 +76,40 @@ def test_more_than_four_levels(dev):
     assert rel_err(cb(co.to(dev)).cpu().numpy(), O.lookup_fork_torch(ref, co, 2).numpy()) <= TOL
 
 
+@pytest.mark.parametrize("case", [(0, 1, "fork"), (1, 3, "canon"), (2, 5, "canon"), (5, 2, "fork"), (7, 3, "canon"),
+                                  (3, 5, "fork"), (4, 5, "canon")])
+def test_other_radii_and_level_counts(case, dev):
+    """Radii without a specialised kernel (generic per-tap path), the specialised ones on row-major
+    levels (>= 4), forward and backward incl. d/dcoords, both coordinate conventions."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    r, L, mode = case
+    B, D, H, W = 2, 24, 36, 68
+    rs = np.random.RandomState(100 * r + L)
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    if mode == "fork":
+        con = (rs.rand(B, H * W, 2) * [W + 3, H + 3] - 1.5).astype(np.float32)
+    else:
+        con = (rs.rand(B, 2, H, W) * [[[W + 3]], [[H + 3]]] - 1.5).astype(np.float32)
+    rd2 = (2 * r + 1) ** 2
+    gn = rs.randn(*((B, H * W, L * rd2) if mode == "fork" else (B, L * rd2, H, W))).astype(np.float32)
+
+    def run(make, device):
+        f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+        co = torch.from_numpy(con).to(device).requires_grad_(True)
+        out = make(f1, f2)(co)
+        out.backward(torch.from_numpy(gn).to(device))
+        return [t.detach().cpu().numpy() for t in (out, f1.grad, f2.grad, co.grad)]
+
+    got = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r), dev)
+    ref = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu")
+    assert got[0].shape == ref[0].shape
+    assert rel_err(got[0], ref[0]) <= TOL
+    assert rel_err(got[1], ref[1]) <= GTOL and rel_err(got[2], ref[2]) <= GTOL
+    assert rel_err(got[3], ref[3]) <= 5e-5
+
+
 def _sintel_inputs():
     g = load_golden("S1_sintel")
     B, D, H, W = (int(v) for v in g["shape"])
