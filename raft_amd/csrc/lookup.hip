@@ -200,6 +200,14 @@ __device__ __forceinline__ size_t fwd4_smem_floats()
 // results are left in LDS as xsink[(l * rd2 + channel) * XS + query] for a GEMM that follows.
 constexpr int XS = QB + 1;
 
+__device__ __forceinline__ unsigned short bf16_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 template <int R, int KIND>
 __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem, int l, int b, int q0, int tid,
                                                   float* xsink = nullptr)
@@ -637,32 +645,52 @@ void corr_lookup_dcoords_kernel(LookupArgs p)
 // convc1 (L*(2r+1)^2 -> Cout) + bias + ReLU (core/update.py:83,90).  The (B, L*rd2, H, W) lookup
 // result is never written: a 1024-thread block runs the four levels' lookups side by side (one
 // 256-thread group per level, same code as the stand-alone kernel), leaves the 32 x Cin result tile
-// in LDS and multiplies it with the weight on the fp32 matrix cores:
-//   out[c][q] = relu( sum_k Wt[c][k] * X[k][q] + bias[c] ),  MFMA 32x32x2: rows = 32 channels,
-//   columns = the block's 32 queries; wave w < Cout/32 owns channel tile w.
-// The weight is pre-packed once (raftcorr_conv1x1_pack_weight) into MFMA-fragment order so that
-// every A fragment is one coalesced dword load per lane.
+// in LDS and multiplies it with the weight on the matrix cores:
+//   out[c][q] = relu( sum_k W[c][k] * X[k][q] + bias[c] ),  rows = 32 channels, columns = the 32 queries.
+// fp32-grade arithmetic at 16-bit matrix-core speed: X and W are split into three bf16 pieces each
+// and the six products of weight >= 2^-16 are accumulated in fp32 (as the bf16x3 build,
+// build_pyramid.hip): 6 x v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 x v_mfma_f32_32x32x2_f32
+// (an fp32-MFMA version of this kernel spent 20 of its 32 us in the product).
+// The weight is pre-split and pre-packed once (raftcorr_conv1x1_pack_weight) into A-fragment order,
+// so every fragment is one coalesced 16-byte load per lane.
 // ---------------------------------------------------------------------------------------------
 struct ConvArgs {
-    const float* wpacked;   // [Cout/32 tiles][ceil(Cin/2) k-steps][64 lanes]
+    const uint4* wpacked;   // [Cout/32 tiles][ceil(Cin/16) k-steps][3 pieces][64 lanes] x 8 bf16
     const float* bias;      // [Cout] or null
     float* out;             // (B, Cout, N)
     int Cin, Cout, relu;
 };
 
 typedef float f32x16l __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8l __attribute__((ext_vector_type(8)));
+
+__host__ __device__ inline int conv_ksteps(int Cin) { return (Cin + 15) / 16; }
+__host__ __device__ inline int conv_xkp(int Cin) { return conv_ksteps(Cin) * 16 + 8; }   // bf16 elements; 16-byte rows whose
+                                                                                         // b128 reads are bank-conflict-free
 
 __global__ __launch_bounds__(256)
-void conv1x1_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin)
+void conv1x1_pack_weight_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin)
 {
-    const int ksteps = (Cin + 1) / 2, tiles = (Cout + 31) / 32;
-    const size_t total = (size_t)tiles * ksteps * 64;
+    const int ks = conv_ksteps(Cin), tiles = (Cout + 31) / 32;
+    const size_t total = (size_t)tiles * ks * 64;                    // one thread = one lane's fragment, all 3 pieces
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int lane = (int)(e & 63);
         const size_t ts = e >> 6;
-        const int s = (int)(ts % ksteps), mt = (int)(ts / ksteps);
-        const int c = mt * 32 + (lane & 31), k = 2 * s + (lane >> 5);
-        packed[e] = (c < Cout && k < Cin) ? w[(size_t)c * Cin + k] : 0.f;
+        const int s = (int)(ts % ks), mt = (int)(ts / ks);
+        const int c = mt * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (c < Cout && k0 + j < Cin) ? w[(size_t)c * Cin + k0 + j] : 0.f;
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            unsigned short h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { h[j] = bf16_rne(x[j]); x[j] -= __uint_as_float((unsigned)h[j] << 16); }
+            uint4 v;
+            v.x = h[0] | ((unsigned)h[1] << 16); v.y = h[2] | ((unsigned)h[3] << 16);
+            v.z = h[4] | ((unsigned)h[5] << 16); v.w = h[6] | ((unsigned)h[7] << 16);
+            packed[((size_t)(mt * ks + s) * 3 + piece) * 64 + lane] = v;
+        }
     }
 }
 
@@ -674,53 +702,84 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
     typedef BlockGeom<R> G;
     constexpr int GF = QB * G::STQ + 2 * QB * G::NB + 5 * QB;       // floats per level group
     constexpr int GFA = (GF + 3) & ~3;
-    float* X = smem + 4 * GFA;                                       // [Cin (+1)][XS]
+    // LDS: region A = the four level groups' tables and tap tiles, later the bf16 pieces of X;
+    //      region B = X in fp32 as the lookups leave it ([k][query]), later the partial sums.
+    const int xkp = conv_xkp(cv.Cin), ks = conv_ksteps(cv.Cin);
+    const int tiles = (cv.Cout + 31) / 32;
+    float* X32 = smem + 4 * GFA;                                     // [Cin][XS]
+    unsigned short* X = (unsigned short*)smem;                       // [3 pieces][QB][xkp] bf16
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int b = blockIdx.z, q0 = blockIdx.x * QB;
     float* gs = smem + grp * GFA;
     if (tid < QB) ((int*)(gs + QB * G::STQ + 2 * QB * G::NB))[4 * QB + tid] = 0;     // spar
-    if (threadIdx.x < XS) X[cv.Cin * XS + threadIdx.x] = 0.f;       // zero row for an odd Cin's last k-step
     __syncthreads();
     if (grp < p.L) {
         switch (grp) {                                               // level l < 4 has layout kind l
-        case 0: lookup_fwd_blocks<R, 0>(p, gs, 0, b, q0, tid, X); break;
-        case 1: lookup_fwd_blocks<R, 1>(p, gs, 1, b, q0, tid, X); break;
-        case 2: lookup_fwd_blocks<R, 2>(p, gs, 2, b, q0, tid, X); break;
-        default: lookup_fwd_blocks<R, 3>(p, gs, 3, b, q0, tid, X); break;
+        case 0: lookup_fwd_blocks<R, 0>(p, gs, 0, b, q0, tid, X32); break;
+        case 1: lookup_fwd_blocks<R, 1>(p, gs, 1, b, q0, tid, X32); break;
+        case 2: lookup_fwd_blocks<R, 2>(p, gs, 2, b, q0, tid, X32); break;
+        default: lookup_fwd_blocks<R, 3>(p, gs, 3, b, q0, tid, X32); break;
         }
     } else {
         __syncthreads();                                             // the two barriers of lookup_fwd_blocks
         __syncthreads();
     }
     __syncthreads();
+    // X (fp32, [k][query]) -> three bf16 pieces in B-fragment order ([piece][query][k], k contiguous);
+    // lanes run along k on both sides: stride-33 reads and consecutive 2-byte writes, conflict-free
+    for (int e = threadIdx.x; e < QB * xkp; e += 1024) {
+        const int qi = e / xkp, k = e - qi * xkp;
+        float o = k < cv.Cin ? X32[k * XS + qi] : 0.f;               // K padding is zero
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            const unsigned short h = bf16_rne(o);
+            X[(size_t)(piece * QB + qi) * xkp + k] = h;
+            o -= __uint_as_float((unsigned)h << 16);
+        }
+    }
+    __syncthreads();
 
     // GEMM: (channel tile, K split) pairs over the 16 waves; partial products meet in LDS (the level
     // groups' tiles are free now), then every thread finishes a few outputs: bias, ReLU, coalesced store
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-    const int tiles = (cv.Cout + 31) / 32, ksteps = (cv.Cin + 1) / 2;
-    const int nsplit = max(1, min(16 / tiles, (4 * GFA) / (tiles * 32 * XS)));   // partial slabs must fit
-    const int kper = (ksteps + nsplit - 1) / nsplit;
-    float* red = smem;                                               // [nsplit][tiles * 32][XS] partial sums
-    constexpr int PB = 16;                                           // weight fragments per batch, two batches in flight
+    const int nsplit = max(1, min(16 / tiles, ks));                  // tiles * nsplit <= 16 slabs (host sizes region B for it)
+    const int kper = (ks + nsplit - 1) / nsplit;
+    float* red = X32;                                                // [nsplit][tiles * 32][XS] partial sums
     for (int pr = wave; pr < tiles * nsplit; pr += 16) {
         const int mt = pr % tiles, sp = pr / tiles;
-        const int s0 = sp * kper, s1 = min(ksteps, s0 + kper);
-        const float* __restrict__ wp = cv.wpacked + (size_t)mt * ksteps * 64 + lane;
-        const float* xb = X + kh * XS + l31;
+        const int s0 = sp * kper, s1 = min(ks, s0 + kper);
+        const uint4* __restrict__ wp = cv.wpacked + (size_t)mt * ks * 3 * 64 + lane;
+        // B fragment (k-step s, piece c): 8 bf16 at X[(c * QB + query) * xkp + 16 s + 8 kh]
+        const uint4* xb = (const uint4*)(X + (size_t)l31 * xkp + 8 * kh);
+        const int xpiece = QB * xkp / 8;                             // uint4 stride between pieces
         f32x16l acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float a_cur[PB], a_nxt[PB];
+        // weight fragments: a ring of PD k-steps in flight (one k-step of MFMAs is shorter than an L2 round trip)
+        constexpr int PD = 4;
+        uint4 a[PD][3];
 #pragma unroll
-        for (int u = 0; u < PB; ++u) a_cur[u] = wp[(size_t)min(s0 + u, ksteps - 1) * 64];
-        for (int s = s0; s < s1; s += PB) {
+        for (int u = 0; u < PD; ++u)
 #pragma unroll
-            for (int u = 0; u < PB; ++u) a_nxt[u] = wp[(size_t)min(s + PB + u, ksteps - 1) * 64];
+            for (int c = 0; c < 3; ++c) a[u][c] = wp[(size_t)(min(s0 + u, ks - 1) * 3 + c) * 64];
+        for (int sb = s0; sb < s1; sb += PD) {
 #pragma unroll
-            for (int u = 0; u < PB; ++u)
-                if (s + u < s1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u], xb[2 * (s + u) * XS], acc, 0, 0, 0);
+            for (int u = 0; u < PD; ++u) {
+                const int s = sb + u;
+                if (s < s1) {                                        // wave-uniform
+                    uint4 xf[3], af[3];
 #pragma unroll
-            for (int u = 0; u < PB; ++u) a_cur[u] = a_nxt[u];
+                    for (int c = 0; c < 3; ++c) { xf[c] = xb[c * xpiece + 2 * s]; af[c] = a[u][c]; }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) a[u][c] = wp[(size_t)(min(s + PD, ks - 1) * 3 + c) * 64];
+                    // small products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                    const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8l, af[pa[t]]),
+                                                                      __builtin_bit_cast(bf16x8l, xf[pb[t]]), acc, 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -741,14 +800,14 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
 
 size_t conv1x1_packed_bytes(int Cout, int Cin)
 {
-    return sizeof(float) * (size_t)((Cout + 31) / 32) * ((Cin + 1) / 2) * 64;
+    return sizeof(uint4) * (size_t)((Cout + 31) / 32) * conv_ksteps(Cin) * 3 * 64;
 }
 
 int launch_conv1x1_pack_weight(const float* w, int Cout, int Cin, float* packed, hipStream_t s)
 {
     const size_t total = conv1x1_packed_bytes(Cout, Cin) / sizeof(float);
-    hipLaunchKernelGGL(conv1x1_pack_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256),
-                       0, s, w, packed, Cout, Cin);
+    hipLaunchKernelGGL(conv1x1_pack_weight_kernel, dim3((unsigned)std::min<size_t>((total / 48 + 255) / 256 + 1, 1024)), dim3(256),
+                       0, s, w, (uint4*)packed, Cout, Cin);
     return check_launch("conv1x1_pack_weight_kernel");
 }
 
@@ -762,10 +821,15 @@ int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r,
     a.lv = lv; a.coords = coords; a.out = nullptr;
     a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = RAFTCORR_MODE_CANONICAL;
     const int rd = 2 * r + 1;
-    ConvArgs c = {wpacked, bias, out, L * rd * rd, Cout, relu};
+    ConvArgs c = {(const uint4*)wpacked, bias, out, L * rd * rd, Cout, relu};
     const int T = 2 * r + 2, NB = T / 2 + 1, TW = 2 * NB;
     const size_t gf = ((size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 5 * QB + 3) & ~(size_t)3;
-    const size_t sm = sizeof(float) * (4 * gf + (size_t)(c.Cin + 1) * XS);
+    const int tiles = (Cout + 31) / 32;
+    const size_t regA = std::max(sizeof(float) * 4 * gf, sizeof(unsigned short) * 3 * QB * (size_t)conv_xkp(c.Cin));
+    const size_t regB = sizeof(float) * XS * std::max<size_t>((size_t)c.Cin, (size_t)std::max(tiles, 16 / std::max(tiles, 1) * tiles) * 32);
+    // the kernel places region B at 4 * gf floats: region A must not be larger than that
+    if (regA > sizeof(float) * 4 * gf) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: Cin = %d too large", c.Cin);
+    const size_t sm = regA + regB;
     if (sm > 160 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: needs %zu bytes of LDS", sm);
     dim3 grid((a.N + QB - 1) / QB, 1, B), block(1024);
     // more than 64 KiB of dynamic LDS needs opting in, once per kernel and device context
