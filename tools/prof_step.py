@@ -17,7 +17,11 @@ with torch.no_grad():
     for _ in range(steps):
         bench.one_pair(f1, f2, coords)
     for _ in range(steps):                                   # the path's other kernels, same shape
-        CorrBlock(f1, f2, num_levels=bench.LEVELS, radius=bench.RADIUS, precision="bf16")
+        for prec in ("bf16", "bf16x3", "fp16x2"):
+            CorrBlock(f1, f2, num_levels=bench.LEVELS, radius=bench.RADIUS, precision=prec)
+        cbf = CorrBlock(f1, f2, num_levels=bench.LEVELS, radius=bench.RADIUS)
+        wt = torch.randn(256, bench.LEVELS * (2 * bench.RADIUS + 1) ** 2, device=dev) / 18
+        cbf.lookup_conv1x1(coords[1], wt, torch.zeros(256, device=dev))
         alt = AlternateCorrBlock(f1, f2, num_levels=bench.LEVELS, radius=bench.RADIUS)
         alt(coords[0]); alt(coords[2])
 g1, g2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
