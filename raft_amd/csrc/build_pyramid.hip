@@ -78,12 +78,20 @@ void corr_pack_kernel(PackArgs p)
     const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
     float* __restrict__ dst = (second ? p.f2p + ((size_t)b * p.tilesN + tile) * p.Dpad * 128
                                       : p.f1p + ((size_t)b * p.tilesM + tile) * p.Dpad * 128) + c;
-    const int per = p.Dpad / PACK_KSPLIT;                 // Dpad is a multiple of 32
+    const int per = p.Dpad / PACK_KSPLIT;                 // Dpad is a multiple of 64
     const int k0 = blockIdx.y * per + kp;
-#pragma unroll 4
-    for (int i = 0; i < per / 2; ++i) {
-        const int k = k0 + 2 * i;
-        dst[(size_t)k * 128] = (t >= 0 && k < p.D) ? src[(size_t)k * N] : 0.f;
+    for (int i0 = 0; i0 < per / 2; i0 += 8) {             // 8 loads in flight per thread (latency-bound pass)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 2 * (i0 + u);
+            v[u] = (t >= 0 && k < p.D && i0 + u < per / 2) ? src[(size_t)min(k, p.D - 1) * N] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 2 * (i0 + u);
+            if (i0 + u < per / 2) dst[(size_t)k * 128] = v[u];
+        }
     }
 }
 
