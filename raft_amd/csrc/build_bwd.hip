@@ -11,6 +11,7 @@
 // is an elementwise pass and the contractions run over the padded column range unchecked.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace raftcorr {
 
@@ -283,6 +284,192 @@ void gemm_f32_kernel(GemmArgs p)
         }
 }
 
+// The same GEMM on the 16-bit matrix cores at fp32-grade accuracy: both operands are split into
+// three bf16 pieces while they are staged (x = hi + mid + lo, 24 significand bits) and the six
+// products of weight >= 2^-16 are accumulated in fp32 (the bf16x3 scheme of build_pyramid.hip):
+// 24 v_mfma_f32_32x32x16_bf16 per 16 k and wave instead of 32 v_mfma_f32_32x32x2_f32 at twice the
+// cycles each.  LDS image per operand: [piece][k group of 8][row 128] x 16 bytes = one MFMA fragment
+// slot per (k group, row); k-group planes are padded by 32 bytes so that the staging writes of
+// lanes that run along k do not collide.  Needs 16-byte loads (vecA && vecB); the fp32 kernel
+// above remains for operands that are not aligned.
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+
+typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+
+// x -> three bf16 pieces, two values per v_cvt_pk_bf16_f32 (round to nearest even in hardware)
+__device__ __forceinline__ void split3(const float (&x)[8], uint4 (&out)[3])
+{
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2g v = {r[2 * j], r[2 * j + 1]};
+            const bf16x2g h = __builtin_convertvector(v, bf16x2g);
+            w[j] = __builtin_bit_cast(unsigned, h);
+            if (c < 2) {
+                r[2 * j] -= __uint_as_float(w[j] << 16);
+                r[2 * j + 1] -= __uint_as_float(w[j] & 0xffff0000u);
+            }
+        }
+        out[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <bool B_K_CONTIG>
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16x3_kernel(GemmArgs p)
+{
+    constexpr int TM = 128, TN = 128, TK = 32;
+    constexpr int PLANE = 128 + 2;                    // uint4 slots per k-group plane (2 slots = 32 B of padding)
+    constexpr int OPU = 3 * 4 * PLANE;                // uint4 slots per operand image
+    __shared__ uint4 As[OPU];
+    __shared__ uint4 Bs[OPU];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM;
+    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
+    const int M = p.M, N = p.N;
+    const float* __restrict__ Ab = p.A + bz * p.sA;
+    const float* __restrict__ Bb = p.B + bz * p.sB;
+    float* __restrict__ C = p.C + bz * p.sC;
+    auto desc = [](const float* base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    };
+
+    // staging registers: K-contiguous operand: 2 slots x 8 k (two 16-byte loads each);
+    // n-contiguous B: 2 slots (column tid & 127, k groups (tid >> 7) and + 2) x 8 dword loads
+    float xa[2][8], xb[2][8];
+    auto gload = [&](int k0) {
+        {
+            const __amdgpu_buffer_rsrc_t rs = desc(Ab + (size_t)m0 * p.lda + k0);
+            const int kg = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = gemm_quad(rs, m0 + r < M, (size_t)r * p.lda, 8 * kg + 4 * h, kend - k0, 1);
+                    xa[i][4 * h] = v.x; xa[i][4 * h + 1] = v.y; xa[i][4 * h + 2] = v.z; xa[i][4 * h + 3] = v.w;
+                }
+            }
+        }
+        if (B_K_CONTIG) {
+            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)n0 * p.ldb + k0);
+            const int kg = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = gemm_quad(rs, n0 + r < N, (size_t)r * p.ldb, 8 * kg + 4 * h, kend - k0, 1);
+                    xb[i][4 * h] = v.x; xb[i][4 * h + 1] = v.y; xb[i][4 * h + 2] = v.z; xb[i][4 * h + 3] = v.w;
+                }
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)k0 * p.ldb + n0);
+            const int col = tid & 127;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kg = (tid >> 7) + 2 * i;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * kg + j;
+                    const bool ok = k0 + k < kend && n0 + col < N;
+                    xb[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rs, ok ? (unsigned)(((size_t)k * p.ldb + col) * 4) : GOOB, 0, 0));
+                }
+            }
+        }
+    };
+    auto lstore = [&]() {
+        uint4 pc[3];
+        {
+            const int kg = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split3(xa[i], pc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) As[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+            }
+        }
+        if (B_K_CONTIG) {
+            const int kg = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split3(xb[i], pc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Bs[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split3(xb[i], pc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Bs[(c * 4 + (tid >> 7) + 2 * i) * PLANE + (tid & 127)] = pc[c];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int kh = lane >> 5, l31 = lane & 31;
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + TK < kend) gload(k0 + TK);
+#pragma unroll
+        for (int st = 0; st < TK / 16; ++st) {
+            // piece of B outermost, small products first: lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi
+            uint4 af[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[c][a] = As[(c * 4 + 2 * st + kh) * PLANE + wm * 64 + a * 32 + l31];
+#pragma unroll
+            for (int cb = 2; cb >= 0; --cb) {
+                uint4 bf[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = Bs[(cb * 4 + 2 * st + kh) * PLANE + wn * 64 + b * 32 + l31];
+#pragma unroll
+                for (int ca = 2 - cb; ca >= 0; --ca)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8g, af[ca][a]), __builtin_bit_cast(bf16x8g, bf[b]), acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + l31;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                if (m < M && n < N) {
+                    if (p.ksplit > 1) atomicAdd(C + (size_t)m * p.ldc + n, acc[a][b][reg]);
+                    else C[(size_t)m * p.ldc + n] = acc[a][b][reg];
+                }
+            }
+        }
+}
+
 // fills the launch-shape fields and runs one batched GEMM; C is zeroed first when K is split
 template <bool B_K_CONTIG>
 static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
@@ -304,8 +491,11 @@ static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
             e = hipMemsetAsync(a.C + b * a.sC, 0, sizeof(float) * (size_t)a.M * a.ldc, s);
         if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, dim3((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit),
-                       dim3(256), 0, s, a);
+    const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit);
+    if (a.vecA && a.vecB && !getenv("RC_BWD_FP32"))          // RC_BWD_FP32: lab knob, forces the fp32-MFMA kernel
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
     return check_launch(what);
 }
 
