@@ -175,16 +175,16 @@ def test_full_size_properties(dev):
         assert torch.equal(out[0, :, aa, bb], exp)
 
 
-def test_largest_baseline_shape_1080p(dev):
-    """BASELINE.json configs[4]: 1088x1920 -> 136x240, N = 32640, 5.7 GB pyramid (offsets beyond
-    2**32 bytes).  Too large for the oracle, so checked through a size-independent known answer:
+def _known_answer_at_integer_coords(dev, H, W, precisions, seed):
+    """Shapes too large for the oracle are checked through a size-independent known answer:
     at coordinates that are integers at every level (multiples of 8) the canonical lookup returns
     pooled-volume entries, and pooling the volume over targets == correlating with the avg-pooled
     fmap2, i.e. out[l, a, b][q] = <f1[:, q], pool_l(f2)[:, y/2^l + b - r, x/2^l + a - r]> / sqrt(D)
-    (0 outside).  fp32 build, bf16 build and the on-the-fly path against that, on sampled queries."""
+    (0 outside).  fp32 build, the on-the-fly path and the listed 16-bit builds against that, on
+    sampled queries."""
     from raft_amd import AlternateCorrBlock, CorrBlock
-    B, D, H, W, L, r = 1, 256, 136, 240, 4, 4
-    g = torch.Generator().manual_seed(1080)
+    B, D, L, r = 1, 256, 4, 4
+    g = torch.Generator().manual_seed(seed)
     f1 = torch.randn(B, D, H, W, generator=g).to(dev)
     f2 = torch.randn(B, D, H, W, generator=g).to(dev)
     xs = (torch.randint(-1, W // 8 + 2, (B, H, W), generator=g) * 8).float()
@@ -218,15 +218,28 @@ def test_largest_baseline_shape_1080p(dev):
     alt = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)(co)
     assert rel_err(sampled(alt), exp) <= TOL
     assert rel_err(alt.cpu().numpy(), full.cpu().numpy()) <= TOL                 # every query, both paths
-    del alt
-    half = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16")(co)
-    assert rel_err(sampled(half), exp) <= 1e-2
-    del half
-    split = CorrBlock(f1, f2, num_levels=L, radius=r, precision="bf16x3")(co)
-    assert rel_err(sampled(split), exp) <= TOL
-    del split
-    split = CorrBlock(f1, f2, num_levels=L, radius=r, precision="fp16x2")(co)
-    assert rel_err(sampled(split), exp) <= TOL
+    del alt, full
+    for prec in precisions:
+        got = CorrBlock(f1, f2, num_levels=L, radius=r, precision=prec)(co)
+        assert rel_err(sampled(got), exp) <= (1e-2 if prec == "bf16" else TOL), prec
+        del got
+
+
+def test_largest_baseline_shape_1080p(dev):
+    """BASELINE.json configs[4]: 1088x1920 -> 136x240, N = 32640, 5.7 GB pyramid (offsets beyond
+    2**32 bytes)."""
+    _known_answer_at_integer_coords(dev, 136, 240, ("bf16", "bf16x3", "fp16x2"), seed=1080)
+
+
+def test_beyond_2_32_elements_2160p(dev):
+    """2160x3840 -> 270x480, N = 129600: level 0 alone is 1.68e10 floats (67 GB), so every element
+    index past the first quarter of the volume needs more than 32 bits; 89 GB pyramid in all.
+    Not a BASELINE.json shape: the maximum-size edge case for the 64-bit offset arithmetic."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs 120 GB of free device memory")
+    _known_answer_at_integer_coords(dev, 270, 480, ("fp16x2",), seed=2160)
+    torch.cuda.empty_cache()
 
 
 def test_step_is_hip_graph_capturable(dev):
