@@ -11,18 +11,21 @@
 // operand shape of v_mfma_f32_32x32x2_f32 (lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]), so no transposes anywhere.
 //
-//   pack    (one small launch) F1 -> [M tile][k][128], F2 -> [patch][k][(j, n)], zero padded:
+//   pack    (one small launch) F1 -> [M tile][k][128], F2 -> [patch][k][cell], zero padded:
 //           tile panels are contiguous, the K loop has no bounds checks and each wave moves
 //           its share with 16-byte direct-to-LDS loads (global_load_lds_dwordx4).
 //   block   256 threads = 4 waves, 128 queries x one 8x16 patch (128 targets)
-//   wave w  32 queries x 128 targets: accumulator n <-> 4x8 tile n of the patch,
-//           MFMA column (lane & 31) <-> cell j of the tile
+//   wave w  32 queries x 128 targets: MFMA column j (lane & 31), accumulator n <-> cell 4j + n of
+//           the patch, so a lane holds one even-aligned 2x2 block of level 0 (16 contiguous bytes)
 //   K loop  BK = 16, two LDS buffers (32 KB per block, 3 blocks per CU), the DMA of tile k+1 in flight while tile k is multiplied,
 //           one barrier per K tile; B fragments of the four accumulators are one ds_read_b128.
-//   epilog  level 0: every store instruction writes two full 128-B lines (one per lane half);
-//           level 1/2: DPP reductions inside the 16-lane rows (quad_perm, row_half_mirror,
-//           row_ror:8); level 3: one cross-row swizzle.  Sums are scaled by exact powers of
-//           two, so the values equal avg_pool2d's up to the order of the three additions.
+//   epilog  level 0: one 16-byte store per lane and accumulator register (32 lanes = 512
+//           contiguous bytes of a query row); level 1: the lane's own four values; level 2: one
+//           DPP quad reduction; level 3: row_half_mirror + one cross-row swizzle.  Levels 2 / 3
+//           have one value per 4 / 16 lanes: the lanes of a group store different registers
+//           (query rows), so all 64 lanes of every store are at work -- 37 store instructions per
+//           wave (the first version: 112, 48 of them mostly masked).  Sums are scaled by exact
+//           powers of two, so the values equal avg_pool2d's up to the order of the three additions.
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -30,6 +33,7 @@
 namespace raftcorr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;      // queries per block
 constexpr int BK = 16;      // K rows per LDS tile of the shipped instantiation (tools/build_lab.hip:
@@ -41,7 +45,8 @@ constexpr int GROUP_M = 8;   // query tiles walked together (L2 reuse of the ope
 // pack: feature maps -> tile-major, zero-padded operand panels
 // ---------------------------------------------------------------------------------------
 //   F1p[b][tile][k][c]        = F1[b][k][tile*128 + c]                  (queries, linear)
-//   F2p[b][patch][k][j*4 + n] = F2[b][k][target(patch, n, j)]           (MFMA B operand order)
+//   F2p[b][patch][k][c]       = F2[b][k][target of cell c of the patch] (patch-tile order, layout.h;
+//                               a lane's float4 of B = the 4 accumulators' columns 4j .. 4j+3)
 // One launch for both operands: grid (tilesM + tilesN, PACK_KSPLIT, B); a thread owns one column
 // of one tile and walks its share of the k rows, so source/destination offsets are computed once
 // and both sides are coalesced along the pixel index.
@@ -68,7 +73,7 @@ void corr_pack_kernel(PackArgs p)
     } else {
         tile -= p.tilesM;
         const int PW = patches_w(p.W);
-        const int n = c & 3, j = c >> 2;
+        const int n = c >> 5, j = c & 31;                 // column c = cell c of the patch: tile n, position j
         const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
         const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
         const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
@@ -108,7 +113,7 @@ int launch_pack_operands(const float* f1, const float* f2, float* f1p, float* f2
 // ---------------------------------------------------------------------------------------
 struct BuildArgs {
     const float* f1p;     // [B][tilesM][Dpad][128]
-    const float* f2p;     // [B][tilesN][Dpad][128], (j, n) interleaved
+    const float* f2p;     // [B][tilesN][Dpad][128], patch-tile order
     float* lvl[4];
     long long slab[4];    // elements per query slab, levels 0..3
     int B, Dpad, N, L;
@@ -149,7 +154,6 @@ __device__ __forceinline__ float dpp(float v)
 constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // i -> 7 - i inside groups of 8
-constexpr int DPP_ROR8 = 0x128;         // i -> (i + 8) & 15 inside a row == xor 8
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_chunk)
 {
@@ -191,6 +195,9 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
                                                int wave, int lane)
 {
     const int kh = lane >> 5, l31 = lane & 31;
+#if defined(RC_LAB_EPI_LOCAL)         // tools/build_lab.hip only: every workgroup stores to tile (0, 0): no HBM write traffic
+    b = 0; tn = 0; m0 = 0;
+#endif
     float unscale = 1.0f;                                      // exact power of two
     if (p.maxpart)
         unscale = ldexpf(1.0f, -(range_exponent(wave_max_of_partials(p.maxpart)) +
@@ -204,7 +211,6 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
     const int rows = min(32, p.N - q0w);
     if (rows <= 0) return;                                   // wave-uniform
     const int L = p.L;
-    const unsigned OOB = 0x80000000u;
     __amdgpu_buffer_rsrc_t r0, r1, r2, r3;
     {
         const size_t qb = (size_t)b * p.N + q0w;
@@ -218,52 +224,66 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
     }
     const unsigned s0b = (unsigned)(p.slab[0] * 4), s1b = (unsigned)(p.slab[1] * 4);
     const unsigned s2b = (unsigned)(p.slab[2] * 4), s3b = (unsigned)(p.slab[3] * 4);
-    const unsigned c0 = (unsigned)(tn * 128 + l31) * 4;                       // + n*128 bytes
-    // pooled-cell offsets (layout.h): lane bits b2 = dy1, b3 = dx1, b4 = dx2 of the level-0 cell
-    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1;
-    const unsigned c1 = (unsigned)(tn * 32 + (lane & 3) * 8 + (b3 | (b2 << 1) | (b4 << 2))) * 4;   // quad lane = n
-    const int n2 = lane & 15;                                                                     // row lane = n
-    const unsigned c2 = (n2 < 4) ? (unsigned)(tn * 8 + (b4 | ((n2 >> 1) << 1) | ((n2 & 1) << 2))) * 4 : OOB;
+    // Lane l31 holds cells 4*l31 .. 4*l31+3 of the patch (accumulator n = cell 4*l31 + n): one
+    // even-aligned 2x2 block of level 0.  Bits of l31 (layout.h): a0 = dy1, a1 = dx1, a2 = dx2,
+    // a3 = column half, a4 = row half of the patch.
+    const int a0 = lane & 1, a1 = (lane >> 1) & 1, a2 = (lane >> 2) & 1, a3 = (lane >> 3) & 1, a4 = (lane >> 4) & 1;
+    const unsigned c0 = (unsigned)(tn * 128 + 4 * l31) * 4;
+    const unsigned c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * 4;
+    const unsigned c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * 4;
     const int ph = tn / p.PW, pwi = tn - ph * p.PW;
-    const unsigned c3 = ((lane & 31) < 2) ? (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + (lane & 31) + (ph & 1) * 2) * 4 : OOB;
-    const int quad = lane & 3, l15 = lane & 15;
+    const unsigned c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * 4;
+    const int quad = lane & 3;
+    const unsigned rowk = 4 * kh;
 
+    f32x16 t2, t3;                                    // vector types: scalar arrays here end up in scratch memory
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { t2[i] = 0.f; t3[i] = 0.f; }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const unsigned row = (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * kh);
+        const unsigned row = (unsigned)((reg & 3) + 8 * (reg >> 2)) + rowk;
         float v[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 4; ++n)
             v[n] = EXACT_MUL ? acc[n][reg] * (p.inv_sqrt_d * unscale) : (acc[n][reg] * unscale) / p.sqrt_d;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[n]), r0, row * s0b + c0 + n * 128, 0, RC_EPI_AUX);
-        }
+        u32x4s w;
+        w.x = __float_as_uint(v[0]); w.y = __float_as_uint(v[1]); w.z = __float_as_uint(v[2]); w.w = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(w, r0, row * s0b + c0, 0, RC_EPI_AUX);    // 32 lanes = 512 contiguous bytes
         if (L > 1) {
-            float t1[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float s = v[n] + dpp<DPP_XOR1>(v[n]);
-                t1[n] = s + dpp<DPP_XOR2>(s);                 // 2x2 sum, in all 4 lanes of the quad
-            }
-            const float lo1 = (quad & 1) ? t1[1] : t1[0], hi1 = (quad & 1) ? t1[3] : t1[2];
-            const float mine1 = (quad & 2) ? hi1 : lo1;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine1 * 0.25f), r1, row * s1b + c1, 0, RC_EPI_AUX);
+            const float t1 = (v[0] + v[1]) + (v[2] + v[3]);                   // the lane's own 2x2 block
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t1 * 0.25f), r1, row * s1b + c1, 0, RC_EPI_AUX);
             if (L > 2) {
-                float t2[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    float s = t1[n] + dpp<DPP_HALF_MIRROR>(t1[n]);
-                    t2[n] = s + dpp<DPP_ROR8>(s);             // 4x4 sum, in all 16 lanes of the row
-                }
-                const float lo2 = (l15 & 1) ? t2[1] : t2[0], hi2 = (l15 & 1) ? t2[3] : t2[2];
-                const float mine2 = (l15 & 2) ? hi2 : lo2;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine2 * 0.0625f), r2, row * s2b + c2, 0, RC_EPI_AUX);
+                const float s = t1 + dpp<DPP_XOR1>(t1);
+                t2[reg] = s + dpp<DPP_XOR2>(s);                               // 4x4 sum, in all 4 lanes of the quad
                 if (L > 3) {
-                    const float u0 = t2[0] + t2[2], u1 = t2[1] + t2[3];      // upper + lower tile
-                    const float mine = (lane & 1) ? u1 : u0;
-                    const float other = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mine), 0x401F));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((mine + other) * 0.015625f), r3, row * s3b + c3, 0, RC_EPI_AUX);
+                    const float u = t2[reg] + dpp<DPP_HALF_MIRROR>(t2[reg]);  // partner a2 ^ 1 (values are quad-uniform)
+                    t3[reg] = u + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(u), 0x401F));   // a4 ^ 1
                 }
             }
+        }
+    }
+    // Levels 2 and 3 have one value per 4 / 16 lanes and register: lanes of a group take different
+    // registers (= query rows), so every store instruction has all 64 lanes at work.
+    if (L > 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                          // registers 4i .. 4i+3 = rows 8i + 4kh + 0..3
+            const float lo = (quad & 1) ? t2[4 * i + 1] : t2[4 * i], hi = (quad & 1) ? t2[4 * i + 3] : t2[4 * i + 2];
+            const float mine = (quad & 2) ? hi : lo;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine * 0.0625f), r2,
+                                                  (unsigned)(8 * i + quad + rowk) * s2b + c2, 0, RC_EPI_AUX);
+        }
+        if (L > 3) {
+            const int rho = (lane & 7) | (a4 << 3);                            // this lane's register among the 16
+            const bool k0 = rho & 1, k1 = rho & 2, k2 = rho & 4, k3 = rho & 8;
+#define RC_SEL2(i) (k0 ? t3[2 * (i) + 1] : t3[2 * (i)])
+#define RC_SEL4(i) (k1 ? RC_SEL2(2 * (i) + 1) : RC_SEL2(2 * (i)))
+#define RC_SEL8(i) (k2 ? RC_SEL4(2 * (i) + 1) : RC_SEL4(2 * (i)))
+            const float mine = k3 ? RC_SEL8(1) : RC_SEL8(0);
+#undef RC_SEL8
+#undef RC_SEL4
+#undef RC_SEL2
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine * 0.015625f), r3,
+                                                  (unsigned)((rho & 3) + 8 * (rho >> 2) + rowk) * s3b + c3, 0, RC_EPI_AUX);
         }
     }
 }
@@ -361,7 +381,7 @@ void corr_build_f32_kernel(BuildArgs p)
 //
 // Operand panels, per tile:  [k-step (16 k)][piece][h = k half][column 128][8 bf16]  (16 B per lane)
 //   lane (r = l & 31, h = l >> 5) of the MFMA holds A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
-//   A columns = the tile's queries; B columns = n*32 + j  (accumulator n, MFMA column j).
+//   A columns = the tile's queries; B slot n*32 + j (accumulator n, MFMA column j) = cell 4j + n of the patch.
 // A K tile (2 k-steps for NP = 1, 1 for NP = 3) is contiguous in the panel and staged like the
 // fp32 kernel's, in 1 KiB DMA pieces.
 // ---------------------------------------------------------------------------------------
@@ -414,7 +434,8 @@ void corr_pack_bf16_kernel(PackArgs p)
     } else {
         tile -= p.tilesM;
         const int PW = patches_w(p.W);
-        const int n = c >> 5, j = c & 31;                                     // column = n*32 + j
+        const int m = (c & 31) * 4 + (c >> 5);            // slot = accumulator*32 + MFMA column <-> cell 4*column + accumulator
+        const int n = m >> 5, j = m & 31;
         const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
         const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
         const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;

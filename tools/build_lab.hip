@@ -27,7 +27,7 @@ template <typename F> float timeit(F launch, int iters = 30)
 
 int main(int argc, char** argv)
 {
-    const int B = 1, D = 256, H = argc > 2 ? atoi(argv[1]) : 55, W = argc > 2 ? atoi(argv[2]) : 128, N = H * W, L = 4;
+    const int B = 1, D = 256, H = argc > 2 ? atoi(argv[1]) : 55, W = argc > 2 ? atoi(argv[2]) : 128, N = H * W, L = getenv("LAB_L") ? atoi(getenv("LAB_L")) : 4;
     BuildArgs a; a.B = B; a.N = N; a.L = L;
     a.tilesM = (N + BM - 1) / BM; a.tilesN = patches_h(H) * patches_w(W); a.nblk_per_b = a.tilesM * a.tilesN;
     a.inv_sqrt_d = 1.f / 16; a.sqrt_d = 16;
