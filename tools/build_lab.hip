@@ -15,6 +15,7 @@ using namespace raftcorr;
 
 template <typename F> float timeit(F launch, int iters = 30)
 {
+    if (getenv("LAB_ITERS")) iters = atoi(getenv("LAB_ITERS"));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i) launch();
     CK(hipDeviceSynchronize());
