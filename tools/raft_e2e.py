@@ -83,7 +83,37 @@ for name, fac in factories.items():
         el = time.perf_counter() - t0
     flows[name] = pad.unpad(up).cpu().numpy()
     res[name] = {"pairs_per_s": n / el, "ms_per_pair": el / n * 1e3, "corr_ms_per_pair": timed.total_ms() / n}
+
+# The same model with the whole forward pass captured once into a HIP graph and replayed: no host
+# launch cost, so the correlation path's share of the GPU time is what is left to see.  (The
+# entry points of libraftcorr.so launch on the caller's stream, allocate nothing and never
+# synchronise, so they are capturable like the stock operators.)
+for name in ("stock_ops_gpu", "all_pairs_fp32", "all_pairs_fp16x2_fused_convc1"):
+    torch.manual_seed(0)
+    model = RAFT(factories[name], fuse_convc1=name.endswith("fused_convc1")).to(dev).eval()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                model(a, b, iters=iters, test_mode=True)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _, up = model(a, b, iters=iters, test_mode=True)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        n, t0 = 20, time.perf_counter()
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    flows[name + "_graph"] = pad.unpad(up).cpu().numpy()
+    res[name + "_graph"] = {"pairs_per_s": n / el, "ms_per_pair": el / n * 1e3,
+                            "note": "whole forward pass replayed as one HIP graph"}
+    del g
 ref = flows["stock_ops_gpu"]
-for name in factories:
+for name in flows:
     res[name]["epe_vs_stock_ops_px"] = float(np.sqrt(((flows[name] - ref) ** 2).sum(1)).mean())
 print(json.dumps(res))
