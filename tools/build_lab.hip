@@ -43,7 +43,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(f1, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(f2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&ws, build_workspace_bytes(B, D, H, W)));
-    a.PW = patches_w(W); a.group_m = GROUP_M; a.Dpad = D;
+    a.PW = patches_w(W); a.group_m = getenv("LAB_GROUP_M") ? atoi(getenv("LAB_GROUP_M")) : GROUP_M; a.Dpad = D;
     dim3 grid(a.nblk_per_b), block(256);
     const double flops = 2.0 * N * (double)N * D;
 #define RUN(name, ...) { float us = timeit([&]() { hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, 0, a); }); printf("%-40s %8.1f us  %6.1f TF (algorithmic)\n", name, us, flops / us * 1e-6); }
