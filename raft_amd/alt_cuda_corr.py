@@ -11,6 +11,7 @@ from . import _lib
 
 
 def _check_input(**tensors):
+    dev = None
     for name, t in tensors.items():
         if not t.is_cuda:
             raise RuntimeError(f"{name} must be a CUDA tensor")       # CHECK_CUDA, correlation.cpp:19
@@ -19,6 +20,10 @@ def _check_input(**tensors):
         if t.dtype != torch.float32:
             # the reference's packed_accessor32<float> throws for any other dtype (kernel.cu:279)
             raise RuntimeError(f"{name} must be float32")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:       # raw pointers below: another GPU's tensor would fault, not raise
+            raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
 
 
 def _dims(fmap1, fmap2, coords):
@@ -52,6 +57,9 @@ def backward(fmap1, fmap2, coords, corr_grad, radius):
     (correlation.cpp:36-48, correlation_kernel.cu:307)."""
     _check_input(fmap1=fmap1, fmap2=fmap2, coords=coords, corr_grad=corr_grad)
     B, N, H1, W1, H2, W2, C = _dims(fmap1, fmap2, coords)
+    rd = 2 * radius + 1
+    if tuple(corr_grad.shape) != (B, N, rd * rd, H1, W1):
+        raise RuntimeError(f"corr_grad must be {(B, N, rd * rd, H1, W1)}; got {tuple(corr_grad.shape)}")
     lib = _lib.load()
     g1 = torch.empty_like(fmap1)
     g2 = torch.empty_like(fmap2)

@@ -21,6 +21,8 @@ feature gradients once, when autograd reaches the build node.
 PyTorch is used for device memory, streams and autograd bookkeeping only; there is no
 fallback path: without the HIP extension every operator raises RuntimeError.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -30,8 +32,6 @@ __all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler"]
 
 _ALIGN = 64   # level offsets inside the packed pyramid buffer, in elements (256 B)
 
-
-import contextlib
 
 _NULL = contextlib.nullcontext()
 
@@ -55,9 +55,16 @@ def _guard(t):
 
 
 def _require_cuda(**tensors):
+    """CHECK_CUDA of correlation.cpp:19, plus: all on ONE device (the kernels take raw pointers, a
+    tensor of another GPU would be a memory fault rather than an error)."""
+    dev = None
     for name, t in tensors.items():
         if not t.is_cuda:
-            raise RuntimeError(f"{name} must be a CUDA tensor")   # CHECK_CUDA, correlation.cpp:19
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
 
 
 def _f32c(t):
@@ -267,6 +274,8 @@ class CorrBlock:
         p = self._pyr
         if not coords.is_cuda:
             raise RuntimeError("coords must be a CUDA tensor")
+        if coords.device != p.device:
+            raise RuntimeError(f"coords is on {coords.device}, the correlation volume on {p.device}")
         nd = coords.dim()
         if nd == 3:                                             # fork semantics, core/corr.py:29-51
             mode = _lib.MODE_FORK
@@ -293,7 +302,9 @@ class CorrBlock:
         (B, Cout, H, W) without materialising the (B, L*rd*rd, H, W) tensor.  Inference only: no
         autograd graph is recorded.  The packed weight is cached on this CorrBlock per weight tensor version."""
         p = self._pyr
-        _require_cuda(coords=coords, weight=weight)
+        _require_cuda(coords=coords, weight=weight, **({} if bias is None else {"bias": bias}))
+        if coords.device != p.device:
+            raise RuntimeError(f"coords is on {coords.device}, the correlation volume on {p.device}")
         if tuple(coords.shape) != (p.B, 2, p.H, p.W):
             raise RuntimeError(f"CorrBlock: coords must be ({p.B}, 2, {p.H}, {p.W}); got {tuple(coords.shape)}")
         cin = self.num_levels * (2 * self.radius + 1) ** 2
@@ -402,8 +413,13 @@ class AlternateCorrBlock:
         self.num_levels = num_levels
         self.radius = radius
         _require_cuda(fmap1=fmap1, fmap2=fmap2)
+        if fmap1.dim() != 4 or fmap1.shape != fmap2.shape:
+            raise RuntimeError(f"AlternateCorrBlock: fmap1/fmap2 must both be (B, D, H, W); got "
+                               f"{tuple(fmap1.shape)} and {tuple(fmap2.shape)}")
         if not 1 <= num_levels <= _lib.MAX_LEVELS:
             raise RuntimeError(f"AlternateCorrBlock: num_levels must be in [1, {_lib.MAX_LEVELS}]")
+        if radius < 0:
+            raise RuntimeError("AlternateCorrBlock: radius must be >= 0")
         fmap1, fmap2 = fmap1.float(), fmap2.float()
         self.pyramid = [(fmap1, fmap2)]                        # core/corr.py:69-73 (L+1 entries)
         for _ in range(self.num_levels):
@@ -416,6 +432,8 @@ class AlternateCorrBlock:
 
     def __call__(self, coords):
         _require_cuda(coords=coords)
+        if coords.device != self._f1.device:
+            raise RuntimeError(f"coords is on {coords.device}, the feature maps on {self._f1.device}")
         B, H, W, C = self._f1.shape
         if coords.shape != (B, 2, H, W):
             raise RuntimeError(f"AlternateCorrBlock: coords must be ({B}, 2, {H}, {W}); got {tuple(coords.shape)}")
