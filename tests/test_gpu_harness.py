@@ -56,6 +56,35 @@ def test_flow_with_fused_convc1_and_split_precision_build(dev, reference_flows):
         assert _epe(ours[it], reference_flows[it]) <= 0.01, f"iteration {it + 1}"
 
 
+def test_flow_on_the_reference_demo_frames(dev):
+    """BASELINE.json configs[0]'s input: the frame pair the reference's demo.py runs on
+    (tests/golden/demo_frames.npz, 436 x 1024 -> the Sintel map 55 x 128), seed-0 random weights.
+    Natural images give smooth, highly self-similar feature maps -- a different regime from the
+    synthetic pair above.  12 iterations, all four blocks against the oracle's CorrBlock."""
+    import os
+    from oracle import corr_oracle as O
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_frames.npz"))
+    i1 = torch.from_numpy(z["frame1"]).permute(2, 0, 1)[None].float().to(dev)
+    i2 = torch.from_numpy(z["frame2"]).permute(2, 0, 1)[None].float().to(dev)
+    pad = InputPadder(i1.shape)
+    a, b = pad.pad(i1, i2)
+    assert a.shape[-2:] == (440, 1024)
+
+    def run(factory, fuse=False):
+        torch.manual_seed(0)
+        model = RAFT(factory, fuse_convc1=fuse).to(dev).eval()
+        with torch.no_grad():
+            return pad.unpad(model(a, b, iters=12)[-1]).cpu().numpy()
+
+    ref = run(lambda x, y: O.CorrBlockOracle(x, y, 4, 4))
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0.1
+    assert _epe(run(lambda x, y: CorrBlock(x, y, num_levels=4, radius=4)), ref) <= 0.01
+    assert _epe(run(lambda x, y: AlternateCorrBlock(x, y, num_levels=4, radius=4)), ref) <= 0.01
+    assert _epe(run(lambda x, y: CorrBlock(x, y, num_levels=4, radius=4, precision="fp16x2"), fuse=True), ref) <= 0.01
+    assert _epe(run(lambda x, y: CorrBlock(x, y, num_levels=4, radius=4, precision="bf16x3")), ref) <= 0.01
+
+
 def test_flow_with_bf16_build_stays_close(dev, reference_flows):
     """precision="bf16": the volume differs by the bf16 input rounding; the flow after 12
     iterations stays within 0.05 px of the fp32 reference on this pair (reported, loose bound)."""
