@@ -155,7 +155,13 @@ def cpu_baseline(seed, budget_s=15.0, cores=None, max_pairs=150):
             el = time.perf_counter() - t0
             if el > budget_s or n >= max_pairs:
                 break
-    return {"value": n / el, "unit": "frame pairs/sec", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+    except OSError:
+        pass
+    return {"value": n / el, "unit": "frame pairs/sec", "cores": cores, "kind": "port", "cpu_model": model,
             "sample": f"{n} pair(s) of the same workload (build + {ITERS} lookups, 55x128, D=256, fp32) "
                       f"in {el:.1f} s with torch.set_num_threads({cores})"}
 
@@ -243,6 +249,8 @@ def main():
         }
         if args.gpus == 1:
             line["extras"] = extras(f1, f2, coords, dev)
+            fill = line["extras"]["hbm_achievable_GBs"]["fill"]          # measured on this box, same process
+            k_lookup["frac_of_measured_fill_rate"] = k_lookup["achieved"] / fill
         line["build_plus_12_lookups_us"] = build_ms * 1e3 + 12 * lookup_ms * 1e3     # the north star's composite
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline_single_core"] = cpu_baseline(1234, budget_s=6.0, cores=1, max_pairs=8)
