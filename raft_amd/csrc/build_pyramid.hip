@@ -17,8 +17,9 @@
 //   block   256 threads = 4 waves, 128 queries x one 8x16 patch (128 targets)
 //   wave w  32 queries x 128 targets: MFMA column j (lane & 31), accumulator n <-> cell 4j + n of
 //           the patch, so a lane holds one even-aligned 2x2 block of level 0 (16 contiguous bytes)
-//   K loop  BK = 16, two LDS buffers (32 KB per block, 3 blocks per CU), the DMA of tile k+1 in flight while tile k is multiplied,
-//           one barrier per K tile; B fragments of the four accumulators are one ds_read_b128.
+//   K loop  BK = 8, two LDS buffers (two __shared__ objects, loop unrolled by two: see the kernel), the DMA
+//           of tile k+1 in flight while tile k is multiplied, one barrier per K tile; B fragments of the
+//           four accumulators are one ds_read_b128.
 //   epilog  level 0: one 16-byte store per lane and accumulator register (32 lanes = 512
 //           contiguous bytes of a query row); level 1: the lane's own four values; level 2: one
 //           DPP quad reduction; level 3: row_half_mirror + one cross-row swizzle.  Levels 2 / 3
@@ -36,8 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;      // queries per block
-constexpr int BK = 16;      // K rows per LDS tile of the shipped instantiation (tools/build_lab.hip:
-                            // BK=16 at 3 waves/SIMD beat BK=32 at 2 and BK=8/16 at 4)
+constexpr int BK = 8;       // K rows per LDS tile of the shipped instantiation (bench.py, after the K loop was
+                            // de-serialised: BK=8 236.7 us, BK=16 238.9 us; BK=32 is slower, tools/build_lab.hip)
 constexpr int WPS = 3;      // waves per SIMD the register allocation is bounded for
 constexpr int GROUP_M = 8;   // query tiles walked together (L2 reuse of the operand panels)
 
@@ -292,7 +293,13 @@ template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD)
 void corr_build_f32_kernel(BuildArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * 128];   // [buf][A|B][k][128]
+    // Two K-tile buffers as two separate __shared__ objects, and the K loop unrolled by two so that
+    // each half names its buffers statically: with one array and a run-time buffer index hipcc cannot
+    // tell the LDS-DMA destination (tile k+1) from the ds_read source (tile k) and waits vmcnt(0)
+    // before the first fragment read -- every wave then sits out the whole fetch latency of the next
+    // tile before it multiplies the current one.
+    __shared__ __attribute__((aligned(16))) float smem0[2 * BK * 128];   // [A|B][k][128]
+    __shared__ __attribute__((aligned(16))) float smem1[2 * BK * 128];
 
     int b, tm, tn;
     block_to_tile(p, b, tm, tn);
@@ -306,9 +313,8 @@ void corr_build_f32_kernel(BuildArgs p)
     const float* __restrict__ pa = p.f1p + ((size_t)b * p.tilesM + tm) * Dpad * 128;
     const float* __restrict__ pb = p.f2p + ((size_t)b * p.tilesN + tn) * Dpad * 128;
 
-    // stage K tile kt into LDS buffer buf: BK x 512 B of A and of B, BK/8 + BK/8 DMA pieces per wave
-    auto stage = [&](int kt, int buf) {
-        float* la = smem + buf * (2 * BK * 128);
+    // stage K tile kt into an LDS buffer: BK x 512 B of A and of B, BK/8 + BK/8 DMA pieces per wave
+    auto stage = [&](int kt, float* la) {
         float* lb = la + BK * 128;
         const float* ga = pa + (size_t)kt * BK * 128;
         const float* gb = pb + (size_t)kt * BK * 128;
@@ -326,17 +332,12 @@ void corr_build_f32_kernel(BuildArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-    const int nk = Dpad / BK;
+    const int nk = Dpad / BK;       // even: Dpad is a multiple of 64
     const int kh = lane >> 5;       // which of the 2 k rows of an MFMA step this lane feeds
     const int l31 = lane & 31;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        __syncthreads();            // tile kt has landed (vmcnt(0) precedes the barrier) and
-                                    // nobody still reads the buffer that is restaged next
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const float* la = smem + buf * (2 * BK * 128) + kh * 128 + wave * 32 + l31;
-        const float* lb = smem + buf * (2 * BK * 128) + BK * 128 + kh * 128 + l31 * 4;
+    auto multiply = [&](const float* tile) {
+        const float* la = tile + kh * 128 + wave * 32 + l31;
+        const float* lb = tile + BK * 128 + kh * 128 + l31 * 4;
         float a_cur = la[0];
         float4 b_cur = *(const float4*)lb;
 #pragma unroll
@@ -354,6 +355,18 @@ void corr_build_f32_kernel(BuildArgs p)
             a_cur = a_nxt;
             b_cur = b_nxt;
         }
+    };
+    stage(0, smem0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        __syncthreads();            // tile kt has landed (vmcnt(0) precedes the barrier) and
+                                    // nobody still reads the buffer that is restaged next
+        stage(kt + 1, smem1);
+        __builtin_amdgcn_sched_barrier(0);      // the DMA is issued here, not sunk below the MFMAs
+        multiply(smem0);
+        __syncthreads();
+        if (kt + 2 < nk) stage(kt + 2, smem0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(smem1);
     }
 
 #if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone

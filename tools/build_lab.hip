@@ -52,6 +52,13 @@ int main(int argc, char** argv)
         a.f1p = f1p; a.f2p = f2p;
         launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
         RUN("fp32 BK=16, 3 waves/SIMD (product)", corr_build_f32_kernel<true, 16, 3>);
+        if (getenv("LAB_SWEEP")) {
+            RUN("fp32 BK=16, 2 waves/SIMD", corr_build_f32_kernel<true, 16, 2>);
+            RUN("fp32 BK=16, 4 waves/SIMD", corr_build_f32_kernel<true, 16, 4>);
+            RUN("fp32 BK=32, 2 waves/SIMD", corr_build_f32_kernel<true, 32, 2>);
+            RUN("fp32 BK=8, 4 waves/SIMD", corr_build_f32_kernel<true, 8, 4>);
+            RUN("fp32 BK=8, 3 waves/SIMD", corr_build_f32_kernel<true, 8, 3>);
+        }
         printf("pack fp32: %.1f us\n", timeit([&]() { launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0); }));
     }
     PackArgs pk{f1, f2, ws, nullptr, D, D, H, W, a.tilesM, a.tilesN, nullptr};
