@@ -519,8 +519,7 @@ void corr_build_bf16_kernel(BuildArgs p)
     const float4* __restrict__ pa = (const float4*)(p.f1p + ((size_t)b * p.tilesM + tm) * panel) +
                                     kh * 128 + wave * 32 + l31;
 
-    auto stage_b = [&](int kt, int buf) {
-        float* lb = smem + buf * OPF;
+    auto stage_b = [&](int kt, float* lb) {
         const float* gb = pb + (size_t)kt * OPF;
 #pragma unroll
         for (int i = 0; i < NP * KS; ++i) {
@@ -545,27 +544,28 @@ void corr_build_bf16_kernel(BuildArgs p)
 #else
     const int nk = p.Dpad / (16 * KS);
 #endif
-    stage_b(0, 0);
+    stage_b(0, smem);
     load_a(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    // restrict-qualified parameters: after inlining, the DMA destination (`other`) and the ds_read
+    // source (`tile`) carry distinct alias scopes
+    auto ktile = [&](int kt, const float* __restrict__ tile, float* __restrict__ other) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KS * NP; ++i) a_cur[i] = a_nxt[i];
 #if defined(RC_LAB_NO_BSTAGE) || defined(RC_LAB_NO_ALOAD)   // tools/build_lab.hip only: ablations
         if (kt + 1 < nk) {
 #if !defined(RC_LAB_NO_BSTAGE)
-            stage_b(kt + 1, buf ^ 1);
+            stage_b(kt + 1, other);
 #endif
 #if !defined(RC_LAB_NO_ALOAD)
             load_a(kt + 1);
 #endif
         }
 #else
-        if (kt + 1 < nk) { stage_b(kt + 1, buf ^ 1); load_a(kt + 1); }
+        if (kt + 1 < nk) { stage_b(kt + 1, other); load_a(kt + 1); }
 #endif
         // B fragment (k-step s, piece c): 16-byte slot (((s * NP + c) * 2 + kh) * 128 + column)
-        const float4* lb = (const float4*)(smem + buf * OPF) + kh * 128 + l31;
+        const float4* lb = (const float4*)tile + kh * 128 + l31;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float4 a[NP];
@@ -588,6 +588,10 @@ void corr_build_bf16_kernel(BuildArgs p)
                     }
             }
         }
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        ktile(kt, smem + buf * OPF, smem + (buf ^ 1) * OPF);
     }
 #if defined(RC_LAB_SKIP_EPILOGUE)      // tools/build_lab.hip only: time the main loop alone
 #pragma unroll

@@ -51,7 +51,7 @@ int main(int argc, char** argv)
         float* f1p = ws; float* f2p = ws + (size_t)B * a.tilesM * D * 128;
         a.f1p = f1p; a.f2p = f2p;
         launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
-        RUN("fp32 BK=16, 3 waves/SIMD (product)", corr_build_f32_kernel<true, 16, 3>);
+        RUN("fp32 (product instantiation)", corr_build_f32_kernel<true, BK, WPS>);
         if (getenv("LAB_SWEEP")) {
             RUN("fp32 BK=16, 2 waves/SIMD", corr_build_f32_kernel<true, 16, 2>);
             RUN("fp32 BK=16, 4 waves/SIMD", corr_build_f32_kernel<true, 16, 4>);
