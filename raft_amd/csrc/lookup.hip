@@ -135,13 +135,17 @@ __device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSm
                                              int b, int q0, int l, int r)
 {
     const int T = 2 * r + 2;
-    auto load_c = [&](int e) -> float {          // coordinate component behind table entry e
+    const bool fork = p.mode == RAFTCORR_MODE_FORK;
+    const float cscale = fork ? 1.0f : 1.0f / (float)(1 << l);       // exact power of two == coords / 2**l
+    // coordinate component behind table entry e, unscaled.  Branch-free (clamped, always valid
+    // address): with a branch per mode hipcc waits vmcnt(0) after every load.
+    auto load_c = [&](int e) -> float {
         const bool isy = e >= QB * T;
         const int ee = isy ? e - QB * T : e;
-        const int q = q0 + min(ee / T, QB - 1);
-        if (q >= p.N || e >= 2 * QB * T) return 0.f;
-        if (p.mode == RAFTCORR_MODE_FORK) return p.coords[((size_t)b * p.N + q) * 2 + (isy ? 1 : 0)];
-        return p.coords[((size_t)b * 2 + (isy ? 1 : 0)) * p.N + q] * (1.0f / (float)(1 << l));
+        const int q = min(q0 + min(ee / T, QB - 1), p.N - 1);
+        const size_t idx = fork ? ((size_t)b * p.N + q) * 2 + (isy ? 1 : 0)
+                                : ((size_t)b * 2 + (isy ? 1 : 0)) * p.N + q;
+        return p.coords[idx];
     };
     auto emit = [&](int e, float c) {
         if (e >= 2 * QB * T) return;
@@ -149,7 +153,7 @@ __device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSm
         const int ee = isy ? e - QB * T : e;
         const int qi = ee / T, k = ee - qi * T;
         int c0; float fc;
-        split_coord(c, c0, fc);
+        split_coord(c * cscale, c0, fc);
         const int v = c0 - r + k;
         if (isy) {
             const bool ok = q0 + qi < p.N && v >= 0 && v < g.h;
@@ -231,18 +235,22 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
         constexpr int NENT = 2 * QB * G::NB;
         constexpr int NTAB = (NENT + 255) / 256;
         float c[NTAB];
+        const bool fork = p.mode == RAFTCORR_MODE_FORK;
+        const float cscale = fork ? 1.0f : 1.0f / (float)(1 << l);       // exact power of two == coords / 2**l
 #pragma unroll
         for (int i = 0; i < NTAB; ++i) {
             const int e = tid + i * 256;
             const bool isy = e >= QB * G::NB;
             const int ee = isy ? e - QB * G::NB : e;
-            const int q = q0 + min(ee / G::NB, QB - 1);
-            c[i] = 0.f;
-            if (q < N && e < NENT) {
-                if (p.mode == RAFTCORR_MODE_FORK) c[i] = p.coords[((size_t)b * N + q) * 2 + (isy ? 1 : 0)];
-                else c[i] = p.coords[((size_t)b * 2 + (isy ? 1 : 0)) * N + q] * (1.0f / (float)(1 << l));
-            }
+            // branch-free: a clamped (always valid) address, every load issued before any is used --
+            // with a branch per mode hipcc waits vmcnt(0) after each load (two serial round trips)
+            const int q = min(q0 + min(ee / G::NB, QB - 1), N - 1);
+            const size_t idx = fork ? ((size_t)b * N + q) * 2 + (isy ? 1 : 0)
+                                    : ((size_t)b * 2 + (isy ? 1 : 0)) * N + q;
+            c[i] = p.coords[idx];
         }
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) c[i] *= cscale;
 #pragma unroll
         for (int i = 0; i < NTAB; ++i) {
             const int e = tid + i * 256;
