@@ -224,7 +224,6 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
     float* sfy = sfx + QB;
     int* xmask = (int*)(sfy + QB);                       // validity bits of the TW tile columns
     int* ymask = xmask + QB;                             // validity bits of the TW tile rows
-    int* spar = ymask + QB;                              // px | py << 1
 
     const LevelGeom g = p.lv.g[l];
     const int N = p.N;
@@ -270,8 +269,9 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             if (k == 0) {
                 const int lo = max(0, -ca), hi = min(G::TW, dim - ca);       // valid cells: [lo, hi)
                 const int m = hi > lo ? (((1 << hi) - 1) & ~((1 << lo) - 1)) : 0;
-                if (isy) { ymask[qi] = m; sfy[qi] = fc; atomicOr(&spar[qi], (cs & 1) << 1); }
-                else     { xmask[qi] = m; sfx[qi] = fc; atomicOr(&spar[qi], cs & 1); }
+                // bit 16: parity of the window origin inside its even-aligned tile
+                if (isy) { ymask[qi] = m | ((cs & 1) << 16); sfy[qi] = fc; }
+                else     { xmask[qi] = m | ((cs & 1) << 16); sfx[qi] = fc; }
             }
         }
     }
@@ -298,8 +298,8 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             if (e >= QB * NBLK) continue;
             const int qi = e / NBLK, blk = e - qi * NBLK;
             const int by = blk / G::NB, bx = blk - by * G::NB;
-            const int xm = off[i] >= 0 ? (xmask[qi] >> (2 * bx)) : 0;
-            const int ym = ymask[qi] >> (2 * by);
+            const int xm = off[i] >= 0 ? ((xmask[qi] & 0xffff) >> (2 * bx)) : 0;
+            const int ym = (ymask[qi] & 0xffff) >> (2 * by);
             float* t = tile + qi * G::STQ + (2 * by) * G::TW + 2 * bx;
             t[0] = ((xm & 1) && (ym & 1)) ? v[i].x : 0.f;
             t[1] = ((xm & 2) && (ym & 1)) ? v[i].y : 0.f;
@@ -323,7 +323,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             const int qi = min(e / rd2, QB - 1), ch = e - (e / rd2) * rd2;
             const int a = ch / G::RD, bb = ch - a * G::RD;
             const float fx = sfx[qi], fy = sfy[qi];
-            const int par = spar[qi];
+            const int par = ((xmask[qi] >> 16) & 1) | (((ymask[qi] >> 16) & 1) << 1);     // px | py << 1
             const float* tp = tile + qi * G::STQ + (bb + (par >> 1)) * G::TW + a + (par & 1);
             o[i] = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
                    tp[G::TW] * ((1.f - fx) * fy) + tp[G::TW + 1] * (fx * fy);
@@ -342,7 +342,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
         const float fx = sfx[qi], fy = sfy[qi];
         const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
         const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-        const int par = spar[qi];
+        const int par = ((xmask[qi] >> 16) & 1) | (((ymask[qi] >> 16) & 1) << 1);         // px | py << 1
         const float* tq = tile + qi * G::STQ + (par >> 1) * G::TW + (par & 1);
         constexpr int NOUT = (rd2 + 7) / 8;
         float o[NOUT];
@@ -480,15 +480,16 @@ __global__ __launch_bounds__(256)
 void corr_lookup_fwd_kernel(LookupArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int kind = p.lv.g[blockIdx.y].kind;    // block-uniform
+    // level l < 4 has layout kind l, deeper levels are row-major (layout.h): the level index alone
+    // selects the code path and, as a literal, makes the level's geometry a fixed kernarg offset --
+    // no dependent scalar load in front of the first vector instruction
+    const int kind = min((int)blockIdx.y, 4);    // block-uniform
     if constexpr (R >= 0) {
-        if (threadIdx.x < QB) ((int*)(smem + QB * BlockGeom<R>::STQ + 2 * QB * BlockGeom<R>::NB))[4 * QB + threadIdx.x] = 0;  // spar
-        __syncthreads();
         switch (kind) {
-        case 0: lookup_fwd_blocks<R, 0>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 1: lookup_fwd_blocks<R, 1>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 2: lookup_fwd_blocks<R, 2>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 3: lookup_fwd_blocks<R, 3>(p, smem, blockIdx.y, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 0: lookup_fwd_blocks<R, 0>(p, smem, 0, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 1: lookup_fwd_blocks<R, 1>(p, smem, 1, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 2: lookup_fwd_blocks<R, 2>(p, smem, 2, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 3: lookup_fwd_blocks<R, 3>(p, smem, 3, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
         default: lookup_fwd_body<R, 4>(p, smem); return;
         }
     } else {
@@ -719,8 +720,6 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int b = blockIdx.z, q0 = blockIdx.x * QB;
     float* gs = smem + grp * GFA;
-    if (tid < QB) ((int*)(gs + QB * G::STQ + 2 * QB * G::NB))[4 * QB + tid] = 0;     // spar
-    __syncthreads();
     if (grp < p.L) {
         switch (grp) {                                               // level l < 4 has layout kind l
         case 0: lookup_fwd_blocks<R, 0>(p, gs, 0, b, q0, tid, X32); break;
