@@ -521,19 +521,55 @@ __device__ __forceinline__ void lookup_bwd_body(const LookupArgs& p, float* smem
     const int C = p.L * rd2;
 
     build_tables<R, KIND>(p, s, geo, b, q0, l, r);
+    // dOut tile -> LDS.  Compile-time radius: clamped (always valid) addresses, every load of the
+    // thread issued before the first is used; a "valid ? load : 0" per element makes hipcc branch
+    // around each load and wait for it -- eleven serial round trips per thread.
+    const int qlast = N - 1 - q0;                                   // last valid query of the block, >= 0
     if (p.mode == RAFTCORR_MODE_FORK) {
         const float* __restrict__ d = p.dout + ((size_t)b * N + q0) * C + l * rd2;
-        for (int e = tid; e < QB * rd2; e += 256) {
-            const int qi = e / rd2;
-            const int ch = e - qi * rd2;
-            g[qi * SG + ch] = (q0 + qi < N) ? d[(size_t)qi * C + ch] : 0.f;
+        if (R >= 0) {
+            constexpr int Rc = R >= 0 ? R : 0;
+            constexpr int RD2 = (2 * Rc + 1) * (2 * Rc + 1), NLD = (QB * RD2 + 255) / 256;
+            float dv[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int e = min(tid + i * 256, QB * RD2 - 1);
+                const int qi = e / RD2, ch = e - qi * RD2;
+                dv[i] = d[(size_t)min(qi, qlast) * C + ch];
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + i * 256;
+                const int qi = e / RD2, ch = e - qi * RD2;
+                if (e < QB * RD2) g[qi * SG + ch] = (qi <= qlast) ? dv[i] : 0.f;
+            }
+        } else {
+            for (int e = tid; e < QB * rd2; e += 256) {
+                const int qi = e / rd2;
+                const int ch = e - qi * rd2;
+                g[qi * SG + ch] = (q0 + qi < N) ? d[(size_t)qi * C + ch] : 0.f;
+            }
         }
     } else {
         const float* __restrict__ d = p.dout + ((size_t)b * C + l * rd2) * N + q0;
         const int qi = tid & (QB - 1);
         const bool vq = q0 + qi < N;
-        for (int ch = tid / QB; ch < rd2; ch += 256 / QB)
-            g[qi * SG + ch] = vq ? d[(size_t)ch * N + qi] : 0.f;
+        if (R >= 0) {
+            constexpr int Rc = R >= 0 ? R : 0;
+            constexpr int RD2 = (2 * Rc + 1) * (2 * Rc + 1), NLD = (RD2 + 256 / QB - 1) / (256 / QB);
+            float dv[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                dv[i] = d[(size_t)min(tid / QB + i * (256 / QB), RD2 - 1) * N + min(qi, qlast)];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = tid / QB + i * (256 / QB);
+                if (ch < RD2) g[qi * SG + ch] = vq ? dv[i] : 0.f;
+            }
+        } else {
+            for (int ch = tid / QB; ch < rd2; ch += 256 / QB)
+                g[qi * SG + ch] = vq ? d[(size_t)ch * N + qi] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -589,7 +625,7 @@ __global__ __launch_bounds__(256)
 void corr_lookup_bwd_kernel(LookupArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    switch (p.dlv.g[blockIdx.y].kind) {
+    switch (min((int)blockIdx.y, 4)) {          // level l < 4 has layout kind l (layout.h)
     case 0: lookup_bwd_body<R, 0>(p, smem); break;
     case 1: lookup_bwd_body<R, 1>(p, smem); break;
     case 2: lookup_bwd_body<R, 2>(p, smem); break;
