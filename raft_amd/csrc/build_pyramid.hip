@@ -464,10 +464,9 @@ void corr_pack_bf16_kernel(PackArgs p)
     for (int g = blockIdx.y * per + gp; g < (blockIdx.y + 1) * per; g += 2) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = g * 8 + j;
-            x[j] = (t >= 0 && k < p.D) ? src[(size_t)k * N] * rscale : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) x[j] = src[(size_t)min(g * 8 + j, p.D - 1) * N];   // always a valid address: all 8 in flight
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (t >= 0 && g * 8 + j < p.D) ? x[j] * rscale : 0.f;
 #pragma unroll
         for (int piece = 0; piece < NP; ++piece) {
             unsigned short h[8];
