@@ -344,20 +344,37 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
         const float w10 = (1.f - fx) * fy, w11 = fx * fy;
         const int par = ((xmask[qi] >> 16) & 1) | (((ymask[qi] >> 16) & 1) << 1);         // px | py << 1
         const float* tq = tile + qi * G::STQ + (par >> 1) * G::TW + (par & 1);
-        constexpr int NOUT = (rd2 + 7) / 8;
-        float o[NOUT];
+        // The 8 threads of a query (g8 = tid / QB) each take one window column a = g8: its RD outputs
+        // share taps vertically, 2 (RD + 1) LDS reads for RD outputs instead of 4 RD.  Columns >= 8
+        // (RD = 9: one) are dealt out by row.  All LDS reads of the thread are in flight together.
+        constexpr int RD = G::RD, TW = G::TW;
+        constexpr int NCOL = RD < 8 ? RD : 8;                 // columns handled whole
+        constexpr int NEX = (RD - NCOL) * ((RD + 7) / 8);     // outputs of the leftover columns, per thread
+        const int g8 = tid / QB;
+        const int a0 = min(g8, NCOL - 1);
+        float c0[RD + 1], c1[RD + 1];
 #pragma unroll
-        for (int i = 0; i < NOUT; ++i) {          // all LDS reads of the thread in flight together
-            const int ch = min(tid / QB + i * 8, rd2 - 1);
-            const int a = ch / G::RD, bb = ch - a * G::RD;
-            const float* tp = tq + bb * G::TW + a;
-            o[i] = tp[0] * w00 + tp[1] * w01 + tp[G::TW] * w10 + tp[G::TW + 1] * w11;
+        for (int k = 0; k <= RD; ++k) { c0[k] = tq[k * TW + a0]; c1[k] = tq[k * TW + a0 + 1]; }
+        float ex[NEX > 0 ? NEX : 1];
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            const int a = NCOL + i / ((RD + 7) / 8), bb = min(g8 + 8 * (i % ((RD + 7) / 8)), RD - 1);
+            const float* tp = tq + bb * TW + a;
+            ex[i] = tp[0] * w00 + tp[1] * w01 + tp[TW] * w10 + tp[TW + 1] * w11;
+        }
+        auto emit = [&](int ch, float v) {
+            if (xsink) xsink[(l * rd2 + ch) * XS + qi] = vq ? v : 0.f;
+            else if (vq) __builtin_nontemporal_store(v, &out[(size_t)ch * N + qi]);
+        };
+        if (g8 < NCOL) {
+#pragma unroll
+            for (int bb = 0; bb < RD; ++bb)
+                emit(g8 * RD + bb, c0[bb] * w00 + c1[bb] * w01 + c0[bb + 1] * w10 + c1[bb + 1] * w11);
         }
 #pragma unroll
-        for (int i = 0; i < NOUT; ++i) {
-            const int ch = tid / QB + i * 8;
-            if (xsink) { if (ch < rd2) xsink[(l * rd2 + ch) * XS + qi] = vq ? o[i] : 0.f; }
-            else if (vq && ch < rd2) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
+        for (int i = 0; i < NEX; ++i) {
+            const int a = NCOL + i / ((RD + 7) / 8), bb = g8 + 8 * (i % ((RD + 7) / 8));
+            if (bb < RD) emit(a * RD + bb, ex[i]);
         }
     }
     RC_STAMP(3);
