@@ -282,7 +282,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
         constexpr int NBLK = G::NB * G::NB;
         constexpr int NIT = (QB * NBLK + 255) / 256;
         float4 v[NIT];
-        int off[NIT];
+        int off[NIT], xmk[NIT], ymk[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int e = tid + i * 256;
@@ -291,6 +291,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             const int o = bytab[qi * G::NB + by] + bxtab[qi * G::NB + bx];
             off[i] = (e < QB * NBLK && o >= 0) ? o : -1;
             v[i] = *(const float4*)(vol + max(o, 0));     // absent blocks read a valid dummy address
+            xmk[i] = xmask[qi]; ymk[i] = ymask[qi];       // read now: no LDS round trip once the taps have landed
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -298,8 +299,8 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             if (e >= QB * NBLK) continue;
             const int qi = e / NBLK, blk = e - qi * NBLK;
             const int by = blk / G::NB, bx = blk - by * G::NB;
-            const int xm = off[i] >= 0 ? ((xmask[qi] & 0xffff) >> (2 * bx)) : 0;
-            const int ym = (ymask[qi] & 0xffff) >> (2 * by);
+            const int xm = off[i] >= 0 ? ((xmk[i] & 0xffff) >> (2 * bx)) : 0;
+            const int ym = (ymk[i] & 0xffff) >> (2 * by);
             float* t = tile + qi * G::STQ + (2 * by) * G::TW + 2 * bx;
             t[0] = ((xm & 1) && (ym & 1)) ? v[i].x : 0.f;
             t[1] = ((xm & 2) && (ym & 1)) ? v[i].y : 0.f;
