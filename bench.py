@@ -194,19 +194,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One step = one frame pair: build, then ITERS lookups.  The pair's CorrBlock is a local of the
+    # step, released before the next pair's is built -- as in RAFT.forward (core/raft.py:103-129),
+    # where corr_fn lives for one forward pass -- so the caching allocator hands every build the same
+    # 261 MB block.  HIP events (build / lookup split for the roofline figures) are recorded on every
+    # EV_EVERY-th step of the timed region: each record costs ~3 us of GPU time.
+    EV_EVERY = 4
+
+    def step(e):
+        if e is not None:
+            e[0].record()
+        cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
+        if e is not None:
+            e[1].record()
+        out = None
+        for c in coords:
+            out = cb(c)
+        if e is not None:
+            e[2].record()
+        return out
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            one_pair(f1, f2, coords)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+            step(None)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)]
+              for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
         barrier()
         t0 = time.perf_counter()
         for s in range(args.steps):
-            ev[s][0].record()
-            cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
-            ev[s][1].record()
-            for c in coords:
-                out = cb(c)
-            ev[s][2].record()
+            step(ev[s // EV_EVERY] if s % EV_EVERY == 0 else None)
         barrier()
         elapsed = time.perf_counter() - t0
 

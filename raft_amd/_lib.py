@@ -82,6 +82,26 @@ def load():
         "There is no CPU fallback.")
 
 
+_fast = {}
+
+
+def fast(name):
+    """A second handle of an entry point WITHOUT argtypes, for calls on the per-iteration path: the
+    caller passes prebuilt ctypes objects (c_int, c_void_p, pointer arrays), which skips ctypes'
+    per-argument conversion -- about 1 us of host time per call, as much as a lookup's launch
+    overhead.  Pointers must be wrapped in c_void_p (a bare Python int would be passed as a C int)."""
+    fn = _fast.get(name)
+    if fn is None:
+        load()
+        fn = getattr(ctypes.CDLL(LIB_PATH), name)       # same dlopen handle, separate function object
+        fn.restype = ctypes.c_int
+        _fast[name] = fn
+    return fn
+
+
+C_MODE = {MODE_FORK: ctypes.c_int(MODE_FORK), MODE_CANONICAL: ctypes.c_int(MODE_CANONICAL)}
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().raftcorr_last_error().decode("utf-8", "replace")

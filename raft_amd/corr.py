@@ -22,6 +22,7 @@ PyTorch is used for device memory, streams and autograd bookkeeping only; there 
 fallback path: without the HIP extension every operator raises RuntimeError.
 """
 import contextlib
+import ctypes
 
 import torch
 import torch.nn.functional as F
@@ -48,10 +49,13 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _guard(t):
     """Device guard only when the tensor does not live on the current device (the context
     manager costs more host time than a lookup kernel runs)."""
-    return _NULL if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
+    return _NULL if t.device.index == _current_device() else torch.cuda.device(t.device)
 
 
 def _require_cuda(**tensors):
@@ -86,6 +90,9 @@ class _Pyramid:
             off += (B * self.N * slab + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = max(off, 1)
         self.device = device
+        self.c_dims = tuple(ctypes.c_int(v) for v in (B, H, W, num_levels))     # prebuilt call arguments
+        self._c_radius = {}
+        self._shapes = {}
         self.flat = None          # detached storage of the volume levels
         self.ptrs = None          # ctypes array of level pointers
         self.dflat = None         # gradient accumulator (allocated on first lookup backward)
@@ -93,8 +100,18 @@ class _Pyramid:
         self._index = {}
 
     def out_shape(self, radius, mode):
-        C = self.L * (2 * radius + 1) ** 2
-        return (self.B, self.N, C) if mode == _lib.MODE_FORK else (self.B, C, self.H, self.W)
+        shape = self._shapes.get((radius, mode))
+        if shape is None:
+            C = self.L * (2 * radius + 1) ** 2
+            shape = (self.B, self.N, C) if mode == _lib.MODE_FORK else (self.B, C, self.H, self.W)
+            self._shapes[(radius, mode)] = shape
+        return shape
+
+    def c_radius(self, radius):
+        c = self._c_radius.get(radius)
+        if c is None:
+            c = self._c_radius[radius] = ctypes.c_int(radius)
+        return c
 
     def slabs(self, flat):
         """Per level: (B*N, slab_l) view of the packed buffer (device layout)."""
@@ -179,12 +196,13 @@ class _BuildPyramid(torch.autograd.Function):
 
 
 def _lookup(pyr, coords, radius, mode):
-    lib = _lib.load()
-    shape = pyr.out_shape(radius, mode)
-    out = torch.empty(shape, dtype=torch.float32, device=coords.device)
+    # the per-iteration call: prebuilt ctypes arguments through the argtypes-free handle (_lib.fast)
+    fn = _lib.fast("raftcorr_lookup_fwd")
+    out = coords.new_empty(pyr.out_shape(radius, mode))      # coords is float32 on the volume's device (checked by the caller)
+    cB, cH, cW, cL = pyr.c_dims
     with _guard(coords):
-        rc = lib.raftcorr_lookup_fwd(pyr.ptrs, pyr.B, pyr.H, pyr.W, pyr.L, radius,
-                                     coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
+        rc = fn(pyr.ptrs, cB, cH, cW, cL, pyr.c_radius(radius), ctypes.c_void_p(coords.data_ptr()),
+                _lib.C_MODE[mode], ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream(coords)))
     if rc:
         _lib.check(rc, "lookup_fwd")
     return out
@@ -279,11 +297,11 @@ class CorrBlock:
         nd = coords.dim()
         if nd == 3:                                             # fork semantics, core/corr.py:29-51
             mode = _lib.MODE_FORK
-            if tuple(coords.shape) != (p.B, p.N, 2):
+            if coords.shape != (p.B, p.N, 2):
                 raise RuntimeError(f"CorrBlock: coords must be ({p.B}, {p.N}, 2); got {tuple(coords.shape)}")
         elif nd == 4:                                           # canonical RAFT, core/raft.py:125
             mode = _lib.MODE_CANONICAL
-            if tuple(coords.shape) != (p.B, 2, p.H, p.W):
+            if coords.shape != (p.B, 2, p.H, p.W):
                 raise RuntimeError(f"CorrBlock: coords must be ({p.B}, 2, {p.H}, {p.W}); got {tuple(coords.shape)}")
         else:
             raise RuntimeError("CorrBlock: coords must be (B, N, 2) or (B, 2, H, W)")
