@@ -99,6 +99,17 @@ def fast(name):
     return fn
 
 
+_addr = {}
+
+
+def fn_addr(name):
+    """Address of an entry point (for raft_amd._pyfast, which calls the C ABI directly)."""
+    a = _addr.get(name)
+    if a is None:
+        a = _addr[name] = ctypes.cast(getattr(load(), name), ctypes.c_void_p).value
+    return a
+
+
 C_MODE = {MODE_FORK: ctypes.c_int(MODE_FORK), MODE_CANONICAL: ctypes.c_int(MODE_CANONICAL)}
 
 

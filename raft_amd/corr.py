@@ -29,6 +29,11 @@ import torch.nn.functional as F
 
 from . import _lib
 
+try:                                    # CPython glue for the per-iteration call (csrc/pyfast.c); same C ABI
+    from . import _pyfast
+except ImportError:                     # not built: the ctypes handle below does the same call
+    _pyfast = None
+
 __all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler"]
 
 _ALIGN = 64   # level offsets inside the packed pyramid buffer, in elements (256 B)
@@ -131,6 +136,7 @@ class _Pyramid:
     def attach(self, flat):
         self.flat = flat
         self.ptrs = _lib.ptr_array(self.slabs(flat))
+        self.ptrs_addr = ctypes.addressof(self.ptrs)
 
     def grad_buffer(self):
         if self.dflat is None:
@@ -196,12 +202,17 @@ class _BuildPyramid(torch.autograd.Function):
 
 
 def _lookup(pyr, coords, radius, mode):
-    # the per-iteration call: prebuilt ctypes arguments through the argtypes-free handle (_lib.fast)
-    fn = _lib.fast("raftcorr_lookup_fwd")
+    # the per-iteration call: raftcorr_lookup_fwd through the CPython glue when it is built, else through
+    # the argtypes-free ctypes handle with prebuilt arguments (_lib.fast) -- host cost only, same kernels
     out = coords.new_empty(pyr.out_shape(radius, mode))      # coords is float32 on the volume's device (checked by the caller)
-    cB, cH, cW, cL = pyr.c_dims
     with _guard(coords):
-        rc = fn(pyr.ptrs, cB, cH, cW, cL, pyr.c_radius(radius), ctypes.c_void_p(coords.data_ptr()),
+        if _pyfast is not None:
+            rc = _pyfast.lookup_fwd(_lib.fn_addr("raftcorr_lookup_fwd"), pyr.ptrs_addr, pyr.B, pyr.H, pyr.W,
+                                    pyr.L, radius, coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
+        else:
+            cB, cH, cW, cL = pyr.c_dims
+            rc = _lib.fast("raftcorr_lookup_fwd")(
+                pyr.ptrs, cB, cH, cW, cL, pyr.c_radius(radius), ctypes.c_void_p(coords.data_ptr()),
                 _lib.C_MODE[mode], ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream(coords)))
     if rc:
         _lib.check(rc, "lookup_fwd")

@@ -107,3 +107,24 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libraftcorr.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_fast_call_paths_reach_the_same_entry_point():
+    """The per-iteration lookup call has two host paths (CPython glue raft_amd/_pyfast.so and an
+    argtypes-free ctypes handle); both must hand their arguments to raftcorr_lookup_fwd unchanged.
+    Checked without a GPU through the argument validation (radius < 0 is rejected before any launch)."""
+    import ctypes
+    from raft_amd import _lib, _pyfast
+    lib = _lib.load()
+    ptrs = (ctypes.c_void_p * 4)(16, 32, 48, 64)
+    rc = _pyfast.lookup_fwd(_lib.fn_addr("raftcorr_lookup_fwd"), ctypes.addressof(ptrs), 1, 55, 128, 4, -3,
+                            4096, _lib.MODE_CANONICAL, 8192, None)
+    assert rc == -1 and b"radius = -3" in lib.raftcorr_last_error()
+    c = ctypes.c_int
+    rc = _lib.fast("raftcorr_lookup_fwd")(ptrs, c(1), c(55), c(128), c(4), c(-5), ctypes.c_void_p(4096),
+                                          _lib.C_MODE[_lib.MODE_CANONICAL], ctypes.c_void_p(8192), ctypes.c_void_p(0))
+    assert rc == -1 and b"radius = -5" in lib.raftcorr_last_error()
+    # a wrong level count reaches the same check through both (argument order intact)
+    rc = _pyfast.lookup_fwd(_lib.fn_addr("raftcorr_lookup_fwd"), ctypes.addressof(ptrs), 1, 55, 128, 9, 4,
+                            4096, _lib.MODE_CANONICAL, 8192, 0)
+    assert rc == -1 and b"num_levels = 9" in lib.raftcorr_last_error()
