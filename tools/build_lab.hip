@@ -52,12 +52,21 @@ int main(int argc, char** argv)
         a.f1p = f1p; a.f2p = f2p;
         launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0);
         RUN("fp32 (product instantiation)", corr_build_f32_kernel<true, BK, WPS>);
+        if (getenv("LAB_OCC")) {        // occupancy sensitivity: pad the workgroup's LDS with dynamic shared memory
+            for (int extra : {0, 24 * 1024, 37 * 1024, 64 * 1024, 140 * 1024}) {
+                float us = timeit([&]() { hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, extra, 0, a); });
+                printf("fp32 product kernel + %3d KB dynamic LDS (%d workgroups/CU by LDS): %8.1f us\n", extra / 1024,
+                       160 * 1024 / (16 * 1024 + extra), us);
+            }
+        }
         if (getenv("LAB_SWEEP")) {
             RUN("fp32 BK=16, 2 waves/SIMD", corr_build_f32_kernel<true, 16, 2>);
             RUN("fp32 BK=16, 4 waves/SIMD", corr_build_f32_kernel<true, 16, 4>);
             RUN("fp32 BK=32, 2 waves/SIMD", corr_build_f32_kernel<true, 32, 2>);
             RUN("fp32 BK=8, 4 waves/SIMD", corr_build_f32_kernel<true, 8, 4>);
             RUN("fp32 BK=8, 3 waves/SIMD", corr_build_f32_kernel<true, 8, 3>);
+            RUN("fp32 BK=8, 5 waves/SIMD", corr_build_f32_kernel<true, 8, 5>);
+            RUN("fp32 BK=8, 6 waves/SIMD", corr_build_f32_kernel<true, 8, 6>);
         }
         printf("pack fp32: %.1f us\n", timeit([&]() { launch_pack_operands(f1, f2, f1p, f2p, B, D, D, H, W, a.tilesM, a.tilesN, 0); }));
     }
