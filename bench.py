@@ -104,7 +104,7 @@ def extras(f1, f2, coords, dev):
         for prec, terms, note in (("fp16x2", 3, "fp32-grade: maps range-scaled, 2 fp16 pieces per operand, 3 products (parity <= 1e-5)"),
                                   ("bf16x3", 6, "fp32-grade: 3 bf16 pieces per operand, 6 products (parity <= 1e-5)"),
                                   ("bf16", 1, "operands rounded to bf16 (parity <= 1e-2)")):
-            t = ev_time_us(lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec))
+            t = ev_time_us(lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec), reps=100, warm=30)
             out["build_" + prec] = {"kernel": "corr_build_bf16_kernel (+ pack" + (" + max|x| pass)" if terms == 3 else ")"),
                                     "us_per_launch": t, "bound": "hbm", "achieved": bb / t / 1e3,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bb / t / 1e3 / HBM_PEAK_GBS,
