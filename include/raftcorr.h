@@ -100,6 +100,23 @@ int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2,
                                 float* const* levels, void* workspace, int64_t workspace_bytes,
                                 int precision, void* stream);
 
+/* Allocation-free variant of raftcorr_build_pyramid_prec.  NO COUNTERPART IN THE REFERENCE: it exists
+ * for callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc -- and therefore cannot bring the workspace the other build
+ * entry points ask for.  Same arguments minus the workspace, same kernels, bit-identical results;
+ * the scratch (operand panels + range-pass partial maxima) is a device array built into the library,
+ * RAFTCORR_NOALLOC_MAX_WORKSPACE bytes per GPU, held until the process ends.  The call allocates and
+ * frees nothing (no hipMalloc/hipFree, no allocating library routine); its first call on a device
+ * looks the array's address up once (hipGetSymbolAddress) -- make that call outside graph capture.
+ * Shapes with raftcorr_build_workspace_bytes(B, D, H, W) > RAFTCORR_NOALLOC_MAX_WORKSPACE (e.g. 1080p,
+ * or B = 6 Things crops) are rejected with RAFTCORR_EUNSUPPORTED; Sintel and KITTI at B = 1 fit.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different
+ * streams) race; the array keeps the last call's contents and no call depends on them. */
+#define RAFTCORR_NOALLOC_MAX_WORKSPACE (32u << 20)
+int raftcorr_build_pyramid_noalloc(const float* fmap1, const float* fmap2,
+                                   int B, int D, int H, int W, int num_levels,
+                                   float* const* levels, int precision, void* stream);
+
 /* Replaces CorrBlock.__call__ + utils.bilinear_sampler (core/corr.py:29-51,
  * core/utils/utils.py:57-65): for every query q and level l the (2r+1)^2 window of 4-tap
  * bilinear samples (zero padding) of levels[l][b*N+q] at (x + a - r, y + b - r); output channel

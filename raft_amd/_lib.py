@@ -33,6 +33,8 @@ _SIGNATURES = {
     "raftcorr_build_pyramid_prec": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                      ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64, _c_int,
                                      ctypes.c_void_p], _c_int),
+    "raftcorr_build_pyramid_noalloc": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        ctypes.POINTER(ctypes.c_void_p), _c_int, ctypes.c_void_p], _c_int),
     "raftcorr_conv1x1_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "raftcorr_conv1x1_pack_weight": ([_c_fp, _c_int, _c_int, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_lookup_conv1x1_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,

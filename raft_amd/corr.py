@@ -26,6 +26,7 @@ import ctypes
 
 import torch
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -102,6 +103,7 @@ class _Pyramid:
         self.ptrs = None          # ctypes array of level pointers
         self.dflat = None         # gradient accumulator (allocated on first lookup backward)
         self.dptrs = None
+        self.dtask = None         # autograd graph task that owns the accumulator's contents
         self._index = {}
 
     def out_shape(self, radius, mode):
@@ -139,14 +141,29 @@ class _Pyramid:
         self.ptrs_addr = ctypes.addressof(self.ptrs)
 
     def grad_buffer(self):
+        """The gradient accumulator of the backward pass that is running now.  What an EARLIER backward
+        pass left behind without ever reaching the build node (torch.autograd.grad(out, coords) only, or
+        an exception half way) is dropped, not added to: the buffer carries the id of the graph task that
+        wrote it."""
+        task = _graph_task_id()
         if self.dflat is None:
             self.dflat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
             self.dptrs = _lib.ptr_array(self.slabs(self.dflat))
+        elif self.dtask != task:
+            self.dflat.zero_()
+        self.dtask = task
         return self.dflat
+
+    def pending_grad(self):
+        """True when lookups of the running backward pass have written into the accumulator."""
+        return self.dflat is not None and self.dtask == _graph_task_id()
 
     def release_grad(self):
         self.dflat = None
         self.dptrs = None
+
+
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)
 
 
 def _build(fmap1, fmap2, pyr, precision="fp32"):
@@ -179,13 +196,15 @@ class _BuildPyramid(torch.autograd.Function):
         return flat, anchor
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dflat, danchor):
         fmap1, fmap2 = ctx.saved_tensors
         pyr = ctx.pyr
         if dflat is not None:                       # someone differentiated corr_pyramid directly
             acc = pyr.grad_buffer()
             acc += dflat
-        if pyr.dflat is None:
+        if not pyr.pending_grad():
+            pyr.release_grad()
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None
         lib = _lib.load()
         B, D, H, W = fmap1.shape
@@ -227,6 +246,7 @@ class _Lookup(torch.autograd.Function):
         return _lookup(pyr, coords, radius, mode)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
         pyr = ctx.pyr
@@ -417,6 +437,7 @@ class _AltLookup(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         lib = _lib.load()
         coords, fmap1, *levels = ctx.saved_tensors

@@ -129,6 +129,22 @@ int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2, int B, i
                              workspace_bytes, precision, stream);
 }
 
+int raftcorr_build_pyramid_noalloc(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+                                   int num_levels, float* const* levels, int precision, void* stream)
+{
+    const char* who = "build_pyramid_noalloc";
+    int rc = check_dims(who, B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2) return fail(RAFTCORR_EINVAL, "%s: null feature map", who);
+    if (D < 1) return fail(RAFTCORR_EINVAL, "%s: D = %d", who, D);
+    if (precision < RAFTCORR_PREC_FP32 || precision > RAFTCORR_PREC_FP16X2)
+        return fail(RAFTCORR_EINVAL, "%s: precision = %d", who, precision);
+    LevelSet lv;
+    rc = make_levels(who, levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_build_pyramid_noalloc(fmap1, fmap2, B, D, H, W, num_levels, lv, precision, (hipStream_t)stream);
+}
+
 int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num_levels, int radius,
                         const float* coords, int mode, float* out, void* stream)
 {

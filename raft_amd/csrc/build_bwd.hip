@@ -492,7 +492,11 @@ static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
         if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     }
     const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit);
-    if (a.vecA && a.vecB && !getenv("RC_BWD_FP32"))          // RC_BWD_FP32: lab knob, forces the fp32-MFMA kernel
+    bool split16 = a.vecA && a.vecB;                         // unaligned operands: the fp32-MFMA kernel
+#if defined(RC_LAB)                    // tools/ only: force the fp32-MFMA kernel
+    if (getenv("RC_BWD_FP32")) split16 = false;
+#endif
+    if (split16)
         hipLaunchKernelGGL(gemm_bf16x3_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);

@@ -30,6 +30,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 
 namespace raftcorr {
 
@@ -648,7 +649,9 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     // query tile at a time per XCD keeps each row's concurrently written segment long (measured at
     // 1080p: 1.61 ms vs 2.35 ms with groups of 8; at Sintel size the grouping of 8 is the faster one)
     a.group_m = (bf16 && (double)B * a.N * (double)lv.g[0].slab * 4.0 > 1.0e9) ? 1 : GROUP_M;
-    if (const char* e = getenv("RC_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : GROUP_M;   // lab knob
+#if defined(RC_LAB)                    // tools/ only (tools/Makefile passes -DRC_LAB): never in libraftcorr.so
+    if (const char* e = getenv("RC_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : GROUP_M;
+#endif
     a.nblk_per_b = a.tilesM * a.tilesN;
     float* f1p = (float*)workspace;
     float* f2p = f1p + (size_t)B * a.tilesM * a.Dpad * (bf16 ? 64 * np : 128);
@@ -714,6 +717,61 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
         if (rc) return rc;
     }
     return RAFTCORR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Allocation-free variant (raftcorr_build_pyramid_noalloc, include/raftcorr.h): the operand panels
+// and the fp16 range pass' partial maxima -- the scratch that the other build entry points take as a
+// caller-allocated workspace -- live in a file-scope device array instead, so callers that cannot
+// allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc) need no workspace.
+// Every GPU the library runs on holds its own copy of the array (at its own address) until the
+// process ends.  In host code the array's NAME is only a stand-in: its device address is looked up
+// once per device with hipGetSymbolAddress (that device current) and kept; host code uses that
+// pointer everywhere (kernel arguments), never the name.
+// Nothing in the scratch has to start at zero: the pack kernels write the panels in full (zero
+// padding included) and the range pass writes all of its partial maxima, so a call does not see
+// what the previous call left.  Calls that overlap in time on one GPU (two streams) share the
+// array and race: serialise them.
+// ---------------------------------------------------------------------------------------
+constexpr size_t NOALLOC_SCRATCH_BYTES = RAFTCORR_NOALLOC_MAX_WORKSPACE;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::atomic<void*> g_scratch_ptr[NOALLOC_MAX_DEVICES];   // per device, null until its first call
+
+static int noalloc_scratch(void** out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "build_pyramid_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES)
+        return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid_noalloc: device %d >= %d", dev, NOALLOC_MAX_DEVICES);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {           // first call on this device (two threads racing here look up the same address)
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(RAFTCORR_ELAUNCH, "build_pyramid_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                        hipGetErrorString(e));
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return RAFTCORR_OK;
+}
+
+int launch_build_pyramid_noalloc(const float* f1, const float* f2, int B, int D, int H, int W, int L,
+                                 const LevelSet& lv, int precision, hipStream_t s)
+{
+    const size_t need = build_workspace_bytes(B, D, H, W);
+    if (need > NOALLOC_SCRATCH_BYTES)
+        return fail(RAFTCORR_EUNSUPPORTED,
+                    "build_pyramid_noalloc: B=%d D=%d H=%d W=%d needs %zu bytes of scratch, the built-in array holds %zu "
+                    "(use raftcorr_build_pyramid_prec with a caller-allocated workspace)", B, D, H, W, need,
+                    NOALLOC_SCRATCH_BYTES);
+    void* ptr = nullptr;
+    const int rc = noalloc_scratch(&ptr);
+    if (rc) return rc;
+    return launch_build_pyramid(f1, f2, B, D, H, W, L, lv, ptr, NOALLOC_SCRATCH_BYTES, precision, s);
 }
 
 }  // namespace raftcorr

@@ -8,6 +8,7 @@ Runs only in the build container, where the reference is mounted read-only at
 reference itself never travels to the GPU box.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py full       # only the full-size fixtures K1 / T1 / P1
 
 Fixture ids follow SURVEY.md section 8(c):
   F1  fork-mode forward, L=4, r=4                      (CorrBlock as shipped, corr.py:29-51)
@@ -18,6 +19,11 @@ Fixture ids follow SURVEY.md section 8(c):
       assembled from the reference's own corr pyramid + bilinear_sampler
   C2  C1 + autograd gradients
   S1  Sintel-shaped (D=256, 55x128, L=4, r=4) checksums + sampled rows, both modes
+  K1  KITTI shape (47x156, D=256, L=4, r=4), canonical mode, fractional coords: sampled output
+      rows + gradients (sampled entries + checksums) for a fixed upstream gradient
+  T1  FlyingThings shape (B=6, 50x90), 12 lookups, weighted sum -> one backward pass
+  P1  1080p shape (136x240): 128 sampled queries -- their volume rows built with torch.matmul,
+      pooled with avg_pool2d, sampled with the reference's bilinear_sampler (queries are independent)
 Every fixture keeps all level sizes >= 2: the reference divides by (H_l - 1) / (W_l - 1)
 (utils/utils.py:61-62) and returns NaN for a 1-pixel level.
 Inputs come from numpy's frozen legacy generator (RandomState), so tests can regenerate the
@@ -108,7 +114,76 @@ def canon_case(seed, B, D, H, W, L, r, grad=False, sigma=2.5):
     return res
 
 
+def sampled(a, idx):
+    return a.reshape(-1)[idx]
+
+
+def full_size_cases():
+    """K1 / T1 / P1: the BASELINE.json shapes that the small fixtures do not reach.  Inputs are
+    regenerated by the tests (tests/golden/inputs.py); only sampled outputs are stored."""
+    import torch.nn.functional as F
+    sys.path.insert(0, HERE)
+    import inputs as I
+    torch.set_num_threads(8)
+    L, r = I.L, I.R
+    pick = rs(77)
+    # ---- K1
+    f1n, f2n, con, goutn = I.k1_inputs()
+    f1, f2, co = t(f1n, True), t(f2n, True), t(con, True)
+    cb = CorrBlock(f1, f2, num_levels=L, radius=r)
+    out = canonical_lookup_ref(cb, co, r)
+    out.backward(t(goutn))
+    B, _, H, W = f1n.shape
+    rows = np.sort(pick.choice(H * W, 64, replace=False))
+    gidx = np.sort(pick.choice(f1n.size, 4096, replace=False))
+    save("K1_kitti", rows=rows, out_rows=out[0].reshape(-1, H * W)[:, rows].T, out_sum=out.double().sum().item(),
+         out_abs=out.double().abs().sum().item(), gidx=gidx,
+         dfmap1_s=sampled(f1.grad, gidx), dfmap2_s=sampled(f2.grad, gidx),
+         dfmap1_abs=f1.grad.double().abs().sum().item(), dfmap2_abs=f2.grad.double().abs().sum().item(),
+         dfmap1_max=f1.grad.abs().max().item(), dfmap2_max=f2.grad.abs().max().item(),
+         dcoords=co.grad, num_levels=L, radius=r, shape=np.array(f1n.shape))
+    del cb, out, f1, f2, co
+    # ---- T1
+    f1n, f2n, coords, goutn, wts = I.t1_inputs()
+    f1, f2 = t(f1n, True), t(f2n, True)
+    gout = t(goutn)
+    cb = CorrBlock(f1, f2, num_levels=L, radius=r)
+    B, _, H, W = f1n.shape
+    rows = np.sort(pick.choice(B * H * W, 64, replace=False))      # (b, q) pairs, flattened
+    rec, loss = {}, 0
+    for k, (c, wk) in enumerate(zip(coords, wts)):
+        o = canonical_lookup_ref(cb, t(c), r)
+        loss = loss + wk * (o * gout).sum()
+        if k in (0, 5, 11):
+            rec[f"out_rows_{k}"] = o.detach().permute(0, 2, 3, 1).reshape(B * H * W, -1)[rows].clone()
+        rec[f"out_sum_{k}"] = o.detach().double().sum().item()
+        del o
+    loss.backward()
+    gidx = np.sort(pick.choice(f1n.size, 4096, replace=False))
+    save("T1_things", rows=rows, gidx=gidx, dfmap1_s=sampled(f1.grad, gidx), dfmap2_s=sampled(f2.grad, gidx),
+         dfmap1_abs=f1.grad.double().abs().sum().item(), dfmap2_abs=f2.grad.double().abs().sum().item(),
+         dfmap1_max=f1.grad.abs().max().item(), dfmap2_max=f2.grad.abs().max().item(),
+         num_levels=L, radius=r, shape=np.array(f1n.shape), **rec)
+    del cb, loss, f1, f2
+    # ---- P1
+    f1n, f2n, con, qs = I.p1_inputs()
+    B, D, H, W = f1n.shape
+    f1q = t(f1n).view(D, H * W)[:, qs]                                        # (D, Q)
+    vol = torch.matmul(f1q.t(), t(f2n).view(D, H * W)).view(len(qs), 1, H, W)  # corr.py:59, these queries only
+    vol = vol / torch.sqrt(torch.tensor(D).float())                            # corr.py:61
+    cq = t(con)[0].view(2, H * W)[:, qs].t().reshape(len(qs), 1, 1, 2)         # (Q,1,1,2) (x, y)
+    outs = []
+    d = torch.linspace(-r, r, 2 * r + 1)
+    delta = torch.stack(torch.meshgrid(d, d), axis=-1).view(1, 2 * r + 1, 2 * r + 1, 2)   # corr.py:38-40
+    for i in range(L):
+        outs.append(bilinear_sampler(vol, cq / 2 ** i + delta).view(len(qs), -1))
+        vol = F.avg_pool2d(vol, 2, stride=2)                                   # corr.py:26
+    save("P1_1080p", queries=qs, out_rows=torch.cat(outs, -1), num_levels=L, radius=r, shape=np.array(f1n.shape))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "full":      # K1 / T1 / P1 only (minutes of CPU time)
+        return full_size_cases()
     torch.set_num_threads(1)     # fixed summation order for the record
     # F1 / F2
     save("F1_fork_fwd", **fork_case(0, 2, 16, 16, 24, 4, 4))
@@ -159,6 +234,7 @@ def main():
          out_fork_rows=out_fork[0, rows], out_canon_rows=out_canon[0].reshape(-1, H * W)[:, rows].T,
          out_fork_sum=out_fork.double().sum().item(), out_canon_sum=out_canon.double().sum().item(),
          num_levels=L, radius=r, shape=np.array([B, D, H, W]), **slabs)
+    full_size_cases()
 
 
 if __name__ == "__main__":

@@ -66,3 +66,31 @@ def test_train_step_harness_two_ranks_gloo():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
+
+
+def _run_bench(extra, env_extra=None):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2", **(env_extra or {}))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--device", "cpu", "--steps", "3",
+                          "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_without_torchrun_launches_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun must start two ranks itself (dry mode: gloo, no
+    kernels) and report what actually ran: ranks_seen == n_gpus == 2, never a figure scaled by the flag."""
+    out, line = _run_bench(["--gpus", "2"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["ranks_seen"] == 2 and line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1     # rank 0 only
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    out, line = _run_bench(["--gpus", "2"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and line is None
+    assert "--gpus 2 but 1 rank(s)" in out.stderr
+    out, line = _run_bench([])
+    assert out.returncode == 0 and line["ranks_seen"] == 1 and line["n_gpus"] == 1

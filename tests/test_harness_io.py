@@ -79,3 +79,26 @@ def test_metrics_known_answers():
     assert abs(k["kitti-epe"] - 5.0 / 8) < 1e-12 and abs(k["kitti-f1"] - 100 / 8) < 1e-12   # 5 px > 3 px and > 5 % of 10
     k = fio.kitti_metrics([fl], [gt], [np.concatenate([np.zeros((1, 4)), np.ones((1, 4))])])
     assert k == {"kitti-epe": 0.0, "kitti-f1": 0.0}               # the bad pixel is not valid
+
+
+def test_reference_checkpoint_with_dataparallel_prefix_loads():
+    """core/demo.py:43-46 loads `module.`-prefixed state dicts (saved from nn.DataParallel,
+    core/train.py:342,398-400); RAFT.load_reference_checkpoint must accept them unchanged, and a
+    foreign key must still be an error (strict)."""
+    import pytest
+    import torch
+    from harness.raft_model import RAFT
+    torch.manual_seed(3)
+    src = RAFT(lambda a, b: None)
+    sd = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    dst = RAFT(lambda a, b: None)
+    res = dst.load_reference_checkpoint(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (ka, va), (kb, vb) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    assert sum(p.numel() for p in dst.parameters()) == 5_257_536          # RAFT-basic, SURVEY.md 0.1
+    plain = dict(src.state_dict())                                          # unprefixed dicts load too
+    RAFT(lambda a, b: None).load_reference_checkpoint(plain)
+    sd["module.not_a_parameter"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        RAFT(lambda a, b: None).load_reference_checkpoint(sd)

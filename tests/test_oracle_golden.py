@@ -145,3 +145,60 @@ def test_sintel_shape_checksums():
     assert rel_err(cb(co3)[0, rows].numpy(), g["out_fork_rows"]) <= 2e-6
     oc = cb(co4)[0].reshape(-1, H * W)[:, rows].T.numpy()
     assert rel_err(oc, g["out_canon_rows"]) <= 2e-6
+
+
+# ---- full-size fixtures K1 / T1 / P1 (BASELINE.json configs[2], [3], [4] shapes) -----------------
+
+def _inputs():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs
+    return inputs
+
+
+def test_k1_kitti_oracle_forward_backward():
+    """K1: the oracle (torch restatement) reproduces the reference at 47x156 with fractional
+    coordinates, forward and gradients; the pixel-coordinate float64 restatement stays inside the
+    1e-5 bar there (the reference's normalise -> denormalise round trip grows with W)."""
+    I = _inputs()
+    g = load_golden("K1_kitti")
+    f1n, f2n, con, goutn = I.k1_inputs()
+    f1, f2, co = _t(f1n, True), _t(f2n, True), _t(con, True)
+    out = O.CorrBlockOracle(f1, f2, I.L, I.R)(co)
+    H, W = f1n.shape[-2:]
+    rows = g["rows"]
+    assert rel_err(out.detach()[0].reshape(-1, H * W)[:, rows].T.numpy(), g["out_rows"]) <= 2e-6
+    out.backward(_t(goutn))
+    for name, t in (("dfmap1", f1.grad), ("dfmap2", f2.grad)):
+        err = np.abs(t.numpy().reshape(-1)[g["gidx"]] - g[name + "_s"]).max() / float(g[name + "_max"])
+        assert err <= 2e-6, (name, err)
+        assert abs(t.double().abs().sum().item() - float(g[name + "_abs"])) <= 1e-6 * float(g[name + "_abs"])
+    assert rel_err(co.grad.numpy(), g["dcoords"]) <= 2e-5
+    # pixel-coordinate float64 restatement on the sampled queries only (cheap)
+    pyr = O.build_pyramid_direct(f1n, f2n, I.L)
+    xy = con.transpose(0, 2, 3, 1).reshape(1, H * W, 2)[:, rows]
+    sub = [p[:, rows] for p in pyr]
+    direct = O.lookup_direct(sub, xy, I.R, per_level_scale=True)[0]
+    assert rel_err(direct, g["out_rows"]) <= 1e-5
+
+
+def test_p1_1080p_direct_restatement():
+    """P1: 128 sampled queries of the 136x240 map against the float64 pixel-coordinate restatement:
+    the reference's coordinate round trip at W = 240 stays inside the 1e-5 bar."""
+    I = _inputs()
+    g = load_golden("P1_1080p")
+    f1n, f2n, con, qs = I.p1_inputs()
+    assert np.array_equal(qs, g["queries"])
+    B, D, H, W = f1n.shape
+    f1q = f1n.reshape(D, H * W)[:, qs].astype(np.float64)
+    vol = (f1q.T @ f2n.reshape(D, H * W).astype(np.float64) / np.sqrt(D)).reshape(1, len(qs), H, W)
+    pyr = [vol]
+    for _ in range(I.L - 1):
+        v = pyr[-1]
+        h2, w2 = v.shape[2] // 2, v.shape[3] // 2
+        v = v[:, :, :2 * h2, :2 * w2]
+        pyr.append(0.25 * (v[:, :, 0::2, 0::2] + v[:, :, 0::2, 1::2] + v[:, :, 1::2, 0::2] + v[:, :, 1::2, 1::2]))
+    xy = con[0].reshape(2, H * W)[:, qs].T[None]
+    direct = O.lookup_direct(pyr, xy, I.R, per_level_scale=True)[0]
+    err = rel_err(direct, g["out_rows"])
+    assert err <= 1e-5, err
