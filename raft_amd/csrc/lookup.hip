@@ -47,7 +47,16 @@ struct LookupArgs {
     float* dcoords;     // bwd, optional
     int B, N, L, r;
     int mode;           // RAFTCORR_MODE_*
+    float rcp_w[RAFTCORR_MAX_LEVELS], rcp_h[RAFTCORR_MAX_LEVELS];   // RN(1 / (W_l - 1)), RN(1 / (H_l - 1)) (ref_sample_pos)
 };
+
+static void set_reciprocals(LookupArgs& a)
+{
+    for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) {
+        a.rcp_w[l] = a.lv.g[l].w > 1 ? 1.0f / (float)(a.lv.g[l].w - 1) : 0.f;      // host division: correctly rounded
+        a.rcp_h[l] = a.lv.g[l].h > 1 ? 1.0f / (float)(a.lv.g[l].h - 1) : 0.f;
+    }
+}
 
 __device__ __forceinline__ void load_xy(const LookupArgs& p, int b, int q, int l, float& x, float& y)
 {
@@ -108,6 +117,49 @@ __device__ __forceinline__ int xpart_k(int x)
 
 constexpr int TAB_INVALID = -(1 << 30);    // marks a window row / column outside the level
 
+// Where the reference actually samples.  bilinear_sampler (core/utils/utils.py:61-65) maps every
+// sample position p = coords + delta (core/corr.py:42-44: the window offset is added FIRST, in fp32)
+// to [-1, 1] and grid_sample(align_corners=True) maps it back:
+//     n = 2 p / (dim - 1);  g = n - 1;  ix = (g + 1) * ((dim - 1) / 2)        (each step rounded to fp32)
+// ((dim-1)/2 is exact, so ATen's CPU form above and its CUDA form ((g+1)/2)*(dim-1) round identically.)
+// The round trip moves a sample by O(1e-7 * dim) pixels -- 2e-6 of max|out| at W = 40, but 1e-5 at
+// W = 240 (fixtures K1 / P1, tests/test_oracle_golden.py) -- and differently for each of the 2r+1
+// window offsets: the samples of a window do not share one fractional offset exactly.  This returns
+// ix for window offset `a`, every step one correctly rounded fp32 operation (contraction off), i.e.
+// bit for bit the reference's.  The division uses the host's correctly rounded reciprocal rcp =
+// RN(1 / (dim-1)): q0 = RN(n rcp), r = n - q0 (dim-1) (exact, FMA), q = RN(q0 + r rcp) is the correctly
+// rounded quotient (Markstein); three instructions instead of the IEEE division sequence.
+// Levels one pixel wide / high divide by zero in the reference (NaN); there the pixel position is used.
+__device__ __forceinline__ float ref_sample_pos(float c, int a_minus_r, int dim, float rcp)
+{
+#pragma clang fp contract(off)
+    const float p = c + (float)a_minus_r;
+    if (dim <= 1) return p;
+    const float dm1 = (float)(dim - 1);
+    const float n2 = 2.0f * p;
+    const float q0 = n2 * rcp;
+    const float rem = __builtin_fmaf(-q0, dm1, n2);
+    const float n = __builtin_fmaf(rem, rcp, q0);
+    const float g = n - 1.0f;
+    const float u = g + 1.0f;
+    return u * (0.5f * dm1);
+}
+
+// (low tap, fraction) of window offset a on one axis, relative to `origin` (the cell index of tap 0 of
+// the staged tile): the low tap is floor(ix) and nearly always origin-relative index `nominal`; when
+// the round trip carried ix across an integer it is one off, and when that tap pair is not part of the
+// staged tile (j outside [0, jmax]) the nearest staged pair is used with a fraction slightly outside
+// [0, 1] (linear extrapolation over <= 3e-5 px: an error of second order).
+__device__ __forceinline__ void ref_sample_tap(float c, bool sane, int a, int r, int dim, float rcp, int origin,
+                                               int nominal, float fc, int jmax, int& j, float& t)
+{
+    if (!sane) { j = nominal; t = fc; return; }
+    const float ix = ref_sample_pos(c, a - r, dim, rcp);
+    const int i0 = (int)floorf(ix);
+    j = min(max(i0 - origin, max(nominal - 1, 0)), min(nominal + 1, jmax));
+    t = ix - (float)(origin + j);
+}
+
 struct LookupSmem {
     float* tile;   // fwd: [QB][ST] taps;  bwd: [QB][SG] dOut
     float* sfx; float* sfy;
@@ -130,7 +182,7 @@ __device__ __forceinline__ LookupSmem carve(float* smem, int r, bool bwd)
 
 // phase 0: every thread loads the coordinate it needs itself (the 2r+2 lanes of a query hit the
 // same address) and writes one table entry; one barrier later all address parts are in LDS.
-template <int R, int KIND>
+template <int R, int KIND, int NT = 256>
 __device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSmem& s, const LevelGeom& g,
                                              int b, int q0, int l, int r)
 {
@@ -167,14 +219,14 @@ __device__ __forceinline__ void build_tables(const LookupArgs& p, const LookupSm
     };
     if (R >= 0) {
         constexpr int Rc = R >= 0 ? R : 0;
-        constexpr int NTAB = (2 * QB * (2 * Rc + 2) + 255) / 256;
+        constexpr int NTAB = (2 * QB * (2 * Rc + 2) + NT - 1) / NT;
         float c[NTAB];
 #pragma unroll
-        for (int i = 0; i < NTAB; ++i) c[i] = load_c(threadIdx.x + i * 256);     // loads in flight together
+        for (int i = 0; i < NTAB; ++i) c[i] = load_c(threadIdx.x + i * NT);     // loads in flight together
 #pragma unroll
-        for (int i = 0; i < NTAB; ++i) emit(threadIdx.x + i * 256, c[i]);
+        for (int i = 0; i < NTAB; ++i) emit(threadIdx.x + i * NT, c[i]);
     } else {
-        for (int e = threadIdx.x; e < 2 * QB * T; e += 256) emit(e, load_c(e));
+        for (int e = threadIdx.x; e < 2 * QB * T; e += NT) emit(e, load_c(e));
     }
 }
 
@@ -191,13 +243,15 @@ struct BlockGeom {
     static constexpr int TW = 2 * NB;            // tile side in cells
     static constexpr int STQ = (TW * TW) | 1;    // LDS stride per query (odd: conflict-free)
     static constexpr int RD = 2 * R + 1;
+    // floats of LDS per 32-query block: tile, block-offset tables (x, y), masks (x, y), per-sample
+    // tables: x (low tap, fraction), y (4 row weights)
+    static constexpr int SMEM = QB * STQ + 2 * QB * NB + 2 * QB + 2 * QB * RD + 4 * QB * RD;
 };
 
 template <int R>
 __device__ __forceinline__ size_t fwd4_smem_floats()
 {
-    typedef BlockGeom<R> G;
-    return (size_t)QB * G::STQ + 2 * QB * G::NB + 5 * QB;
+    return (size_t)BlockGeom<R>::SMEM;
 }
 
 // xsink == nullptr: results go to p.out.  Otherwise (fused consumer, canonical mode) the block's
@@ -212,176 +266,227 @@ __device__ __forceinline__ unsigned short bf16_rne(float x)
     return (unsigned short)(u >> 16);
 }
 
-template <int R, int KIND>
+// NT: threads that work on the block's 32 queries.  The stand-alone kernel runs QB * RD of them (R = 4: 288):
+// one thread per (query, window column) in the blend, and the block loads (QB * NB^2), the table entries and
+// the per-sample entries all divide evenly over them.  The fused kernel gives each level a 256-thread group.
+template <int R, int KIND, int NT>
 __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem, int l, int b, int q0, int tid,
                                                   float* xsink = nullptr)
 {
     typedef BlockGeom<R> G;
-    float* tile = smem;                                  // [QB][STQ]
-    int* bxtab = (int*)(smem + QB * G::STQ);             // [QB][NB] x part of the block offset
-    int* bytab = bxtab + QB * G::NB;                     // [QB][NB] y part + query slab offset
-    float* sfx = (float*)(bytab + QB * G::NB);
-    float* sfy = sfx + QB;
-    int* xmask = (int*)(sfy + QB);                       // validity bits of the TW tile columns
-    int* ymask = xmask + QB;                             // validity bits of the TW tile rows
+    constexpr int RD = G::RD, TW = G::TW, NB = G::NB;
+    __builtin_assume(tid >= 0 && tid < NT);
+    float4* wy = (float4*)smem;                          // [QB][RD] weights of tile rows (py + b - 1 .. py + b + 2)
+    float* tile = smem + 4 * QB * RD;                    // [QB][STQ]
+    int* bxtab = (int*)(tile + QB * G::STQ);             // [QB][NB] x part of the block offset
+    int* bytab = bxtab + QB * NB;                        // [QB][NB] y part + query slab offset
+    int* xmask = bytab + QB * NB;                        // validity bits of the TW tile columns
+    int* ymask = xmask + QB;                             // validity bits of the TW tile rows; bit 16: parity py
+    int* sjx = ymask + QB;                               // [QB][RD] low tap of window column a, tile-relative
+    float* stx = (float*)(sjx + QB * RD);                // [QB][RD] fraction of window column a
 
     const LevelGeom g = p.lv.g[l];
     const int N = p.N;
     const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
 
     RC_STAMP(0);
-    {   // phase 0: block-offset tables, masks, fractions
-        constexpr int NENT = 2 * QB * G::NB;
-        constexpr int NTAB = (NENT + 255) / 256;
-        float c[NTAB];
-        const bool fork = p.mode == RAFTCORR_MODE_FORK;
-        const float cscale = fork ? 1.0f : 1.0f / (float)(1 << l);       // exact power of two == coords / 2**l
-#pragma unroll
-        for (int i = 0; i < NTAB; ++i) {
-            const int e = tid + i * 256;
-            const bool isy = e >= QB * G::NB;
-            const int ee = isy ? e - QB * G::NB : e;
-            // branch-free: a clamped (always valid) address, every load issued before any is used --
-            // with a branch per mode hipcc waits vmcnt(0) after each load (two serial round trips)
-            const int q = min(q0 + min(ee / G::NB, QB - 1), N - 1);
-            const size_t idx = fork ? ((size_t)b * N + q) * 2 + (isy ? 1 : 0)
-                                    : ((size_t)b * 2 + (isy ? 1 : 0)) * N + q;
-            c[i] = p.coords[idx];
+    // phase 0: block-offset tables + masks (2 QB NB entries).  The per-sample taps / fractions / row weights
+    // (2 QB RD entries, ref_sample_tap) are computed in phase 1, between the issue of the tap loads and their
+    // arrival -- arithmetic that needs only the coordinates, under memory latency the wave would otherwise
+    // sit out.
+    constexpr int NBE = 2 * QB * NB, NSE = 2 * QB * RD;
+    constexpr int RB = (NBE + NT - 1) / NT, RS = (NSE + NT - 1) / NT;    // rounds of block / sample entries
+    const bool fork = p.mode == RAFTCORR_MODE_FORK;
+    const float cscale = fork ? 1.0f : 1.0f / (float)(1 << l);           // exact power of two == coords / 2**l
+    // coordinate behind entry e of a kind with `per` entries per (axis, query).  Branch-free: a clamped
+    // (always valid) address, every load issued before any is used -- with a branch per mode hipcc
+    // waits vmcnt(0) after each load (serial round trips)
+    auto load_c = [&](int e, int per) -> float {
+        const bool isy = e >= QB * per;
+        const int ee = isy ? e - QB * per : e;
+        const int q = min(q0 + min(ee / per, QB - 1), N - 1);
+        const size_t idx = fork ? ((size_t)b * N + q) * 2 + (isy ? 1 : 0)
+                                : ((size_t)b * 2 + (isy ? 1 : 0)) * N + q;
+        return p.coords[idx];
+    };
+    auto block_entry = [&](int e, float cc) {
+        if (e >= NBE) return;
+        const bool isy = e >= QB * NB;
+        const int ee = isy ? e - QB * NB : e;
+        const int qi = ee / NB, k = ee - qi * NB;
+        int c0; float fc;
+        split_coord(cc, c0, fc);
+        const int cs = c0 - R;                       // first tap of the window
+        const int ca = cs & ~1;                      // even-aligned tile origin
+        const int dim = isy ? g.h : g.w, dimp = isy ? g.hp : g.wp;
+        const int v = ca + 2 * k;                    // first cell of block k
+        const bool ok = v >= 0 && v < dimp && (!isy || q0 + qi < N);
+        if (isy) bytab[ee] = ok ? ypart_k<KIND>(g.pw, g.w, v) + qi * (int)g.slab : TAB_INVALID;
+        else     bxtab[ee] = ok ? xpart_k<KIND>(v) : TAB_INVALID;
+        if (k == 0) {
+            const int lo = max(0, -ca), hi = min(TW, dim - ca);              // valid cells: [lo, hi)
+            const int m = hi > lo ? (((1 << hi) - 1) & ~((1 << lo) - 1)) : 0;
+            if (isy) ymask[qi] = m | ((cs & 1) << 16); else xmask[qi] = m;
         }
-#pragma unroll
-        for (int i = 0; i < NTAB; ++i) c[i] *= cscale;
-#pragma unroll
-        for (int i = 0; i < NTAB; ++i) {
-            const int e = tid + i * 256;
-            if (e >= NENT) continue;
-            const bool isy = e >= QB * G::NB;
-            const int ee = isy ? e - QB * G::NB : e;
-            const int qi = ee / G::NB, k = ee - qi * G::NB;
-            int c0; float fc;
-            split_coord(c[i], c0, fc);
-            const int cs = c0 - R;                       // first tap of the window
-            const int ca = cs & ~1;                      // even-aligned tile origin
-            const int v = ca + 2 * k;                    // first cell of block k
-            const int dim = isy ? g.h : g.w, dimp = isy ? g.hp : g.wp;
-            const bool ok = v >= 0 && v < dimp && (!isy || q0 + qi < N);
-            if (isy) bytab[ee] = ok ? ypart_k<KIND>(g.pw, g.w, v) + qi * (int)g.slab : TAB_INVALID;
-            else     bxtab[ee] = ok ? xpart_k<KIND>(v) : TAB_INVALID;
-            if (k == 0) {
-                const int lo = max(0, -ca), hi = min(G::TW, dim - ca);       // valid cells: [lo, hi)
-                const int m = hi > lo ? (((1 << hi) - 1) & ~((1 << lo) - 1)) : 0;
-                // bit 16: parity of the window origin inside its even-aligned tile
-                if (isy) { ymask[qi] = m | ((cs & 1) << 16); sfy[qi] = fc; }
-                else     { xmask[qi] = m | ((cs & 1) << 16); sfx[qi] = fc; }
-            }
+    };
+    auto sample_entry = [&](int e, float cc) {
+        if (e >= NSE) return;
+        const bool isy = e >= QB * RD;
+        const int ee = isy ? e - QB * RD : e;
+        const int qi = ee / RD, k = ee - qi * RD;
+        int c0; float fc;
+        split_coord(cc, c0, fc);
+        const int cs = c0 - R, ca = cs & ~1;
+        const int n = (cs & 1) + k;                  // nominal low tap of window offset k, tile-relative
+        int j; float t;
+#if defined(RC_LAB_E1)
+        j = n; t = fc;
+#else
+        ref_sample_tap(cc, c0 > -(1 << 23), k, R, isy ? g.h : g.w, isy ? p.rcp_h[l] : p.rcp_w[l], ca, n, fc,
+                       TW - 2, j, t);
+#endif
+        if (!isy) {
+            sjx[ee] = j; stx[ee] = t;
+        } else {
+            // weights of the tile rows n-1 .. n+2: the sample's tap pair is (n, n+1) unless the round
+            // trip carried it across an integer (d = -1 / +1)
+            const int d = j - n;
+            float4 w;
+            w.x = d < 0 ? 1.f - t : 0.f;
+            w.y = d < 0 ? t : (d == 0 ? 1.f - t : 0.f);
+            w.z = d == 0 ? t : (d > 0 ? 1.f - t : 0.f);
+            w.w = d > 0 ? t : 0.f;
+            wy[ee] = w;
         }
-    }
+    };
+    float cb[RB], cs_[RS];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) cb[i] = load_c(tid + i * NT, NB);
+#pragma unroll
+    for (int i = 0; i < RS; ++i) cs_[i] = load_c(tid + i * NT, RD);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) block_entry(tid + i * NT, cb[i] * cscale);
     __syncthreads();
     RC_STAMP(1);
 
     {   // phase 1: 2x2 blocks -> LDS tile, all loads of a thread in flight together
-        constexpr int NBLK = G::NB * G::NB;
-        constexpr int NIT = (QB * NBLK + 255) / 256;
+        constexpr int NBLK = NB * NB;
+        constexpr int NIT = (QB * NBLK + NT - 1) / NT;
+        constexpr bool EVEN = NT % NBLK == 0;             // a thread keeps its block (by, bx), its queries step by NT / NBLK
         float4 v[NIT];
         int off[NIT], xmk[NIT], ymk[NIT];
+        const int qi0 = tid / NBLK, blk0 = tid - qi0 * NBLK;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + i * 256;
-            const int qi = min(e / NBLK, QB - 1), blk = e - (e / NBLK) * NBLK;
-            const int by = blk / G::NB, bx = blk - by * G::NB;
-            const int o = bytab[qi * G::NB + by] + bxtab[qi * G::NB + bx];
+            const int e = tid + i * NT;
+            const int qi = EVEN ? min(qi0 + i * (NT / NBLK), QB - 1) : min(e / NBLK, QB - 1);
+            const int blk = EVEN ? blk0 : e - (e / NBLK) * NBLK;
+            const int by = blk / NB, bx = blk - by * NB;
+            const int o = bytab[qi * NB + by] + bxtab[qi * NB + bx];
             off[i] = (e < QB * NBLK && o >= 0) ? o : -1;
             v[i] = *(const float4*)(vol + max(o, 0));     // absent blocks read a valid dummy address
             xmk[i] = xmask[qi]; ymk[i] = ymask[qi];       // read now: no LDS round trip once the taps have landed
         }
+        __builtin_amdgcn_sched_barrier(0);                // the loads are in flight: now the sample tables
+#pragma unroll
+        for (int i = 0; i < RS; ++i) sample_entry(tid + i * NT, cs_[i] * cscale);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NT;
             if (e >= QB * NBLK) continue;
-            const int qi = e / NBLK, blk = e - qi * NBLK;
-            const int by = blk / G::NB, bx = blk - by * G::NB;
-            const int xm = off[i] >= 0 ? ((xmk[i] & 0xffff) >> (2 * bx)) : 0;
+            const int qi = EVEN ? qi0 + i * (NT / NBLK) : e / NBLK;
+            const int blk = EVEN ? blk0 : e - (e / NBLK) * NBLK;
+            const int by = blk / NB, bx = blk - by * NB;
+            const int xm = off[i] >= 0 ? (xmk[i] >> (2 * bx)) : 0;
             const int ym = (ymk[i] & 0xffff) >> (2 * by);
-            float* t = tile + qi * G::STQ + (2 * by) * G::TW + 2 * bx;
+            float* t = tile + qi * G::STQ + (2 * by) * TW + 2 * bx;
             t[0] = ((xm & 1) && (ym & 1)) ? v[i].x : 0.f;
             t[1] = ((xm & 2) && (ym & 1)) ? v[i].y : 0.f;
-            t[G::TW] = ((xm & 1) && (ym & 2)) ? v[i].z : 0.f;
-            t[G::TW + 1] = ((xm & 2) && (ym & 2)) ? v[i].w : 0.f;
+            t[TW] = ((xm & 1) && (ym & 2)) ? v[i].z : 0.f;
+            t[TW + 1] = ((xm & 2) && (ym & 2)) ? v[i].w : 0.f;
         }
     }
     __syncthreads();
     RC_STAMP(2);
 
-    constexpr int rd2 = G::RD * G::RD;
+    constexpr int rd2 = RD * RD;
     const int C = p.L * rd2;
+    // one sample, the general way: 4 weighted tile rows x 2 columns.  row(i): tile row py + bb - 1 + i,
+    // clamped at 0 (the weight of a row above the tile is zero by construction)
+    auto sample = [&](int qi, int a, int bb) -> float {
+        const float fx = stx[qi * RD + a];
+        const float4 w = wy[qi * RD + bb];
+        const int py = ymask[qi] >> 16;
+        const float* tp = tile + qi * G::STQ + sjx[qi * RD + a];
+        const float* r0 = tp + max(py + bb - 1, 0) * TW;
+        const float* r1 = tp + (py + bb) * TW;
+        const float h0 = r0[0] + fx * (r0[1] - r0[0]), h1 = r1[0] + fx * (r1[1] - r1[0]);
+        const float h2 = r1[TW] + fx * (r1[TW + 1] - r1[TW]), h3 = r1[2 * TW] + fx * (r1[2 * TW + 1] - r1[2 * TW]);
+        return w.x * h0 + w.y * h1 + w.z * h2 + w.w * h3;
+    };
     if (p.mode == RAFTCORR_MODE_FORK) {
         // out (B, N, C): lanes run along the channel dim
         float* __restrict__ out = p.out + ((size_t)b * N + q0) * C + l * rd2;
-        constexpr int NOUT = (QB * rd2 + 255) / 256;
-        float o[NOUT];
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) {
-            const int e = tid + i * 256;
-            const int qi = min(e / rd2, QB - 1), ch = e - (e / rd2) * rd2;
-            const int a = ch / G::RD, bb = ch - a * G::RD;
-            const float fx = sfx[qi], fy = sfy[qi];
-            const int par = ((xmask[qi] >> 16) & 1) | (((ymask[qi] >> 16) & 1) << 1);     // px | py << 1
-            const float* tp = tile + qi * G::STQ + (bb + (par >> 1)) * G::TW + a + (par & 1);
-            o[i] = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
-                   tp[G::TW] * ((1.f - fx) * fy) + tp[G::TW + 1] * (fx * fy);
-        }
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) {
-            const int e = tid + i * 256;
+#pragma unroll 2
+        for (int e = tid; e < QB * rd2; e += NT) {        // (few samples in flight: each one is 14 LDS reads)
             const int qi = e / rd2, ch = e - qi * rd2;
-            if (e < QB * rd2 && q0 + qi < N) __builtin_nontemporal_store(o[i], &out[(size_t)qi * C + ch]);
+            const int a = ch / RD;
+            const float o = sample(qi, a, ch - a * RD);
+            if (q0 + qi < N) __builtin_nontemporal_store(o, &out[(size_t)qi * C + ch]);
         }
     } else {
-        // out (B, C, N): lanes run along the query dim
-        float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
-        const int qi = tid & (QB - 1);
+        // out (B, C, N): lanes run along the query dim.  A query's NT / QB threads each take one window column
+        // a: the column is blended horizontally once for each of the RD + 3 tile rows its samples can touch (2
+        // LDS reads per row), then every output is four weighted rows (one 16-byte LDS read of weights) -- no
+        // selects, no dynamic register indices.  Columns beyond NT / QB (fused kernel, RD = 9: one) are dealt
+        // out by row.  (Non-temporal global stores; the same stores through a buffer descriptor with a scalar
+        // channel offset cost 1.4 us more per launch at Sintel size, tools/lookup_time.hip.)
+        constexpr int TPQ = NT / QB;
+        constexpr int NCOL = RD < TPQ ? RD : TPQ;             // columns handled whole
+        constexpr int NEX = (RD - NCOL) * ((RD + TPQ - 1) / TPQ);   // outputs of the leftover columns, per thread
+        const int qi = tid & (QB - 1), g8 = tid / QB;
         const bool vq = q0 + qi < N;
-        const float fx = sfx[qi], fy = sfy[qi];
-        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
-        const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-        const int par = ((xmask[qi] >> 16) & 1) | (((ymask[qi] >> 16) & 1) << 1);         // px | py << 1
-        const float* tq = tile + qi * G::STQ + (par >> 1) * G::TW + (par & 1);
-        // The 8 threads of a query (g8 = tid / QB) each take one window column a = g8: its RD outputs
-        // share taps vertically, 2 (RD + 1) LDS reads for RD outputs instead of 4 RD.  Columns >= 8
-        // (RD = 9: one) are dealt out by row.  All LDS reads of the thread are in flight together.
-        constexpr int RD = G::RD, TW = G::TW;
-        constexpr int NCOL = RD < 8 ? RD : 8;                 // columns handled whole
-        constexpr int NEX = (RD - NCOL) * ((RD + 7) / 8);     // outputs of the leftover columns, per thread
-        const int g8 = tid / QB;
         const int a0 = min(g8, NCOL - 1);
-        float c0[RD + 1], c1[RD + 1];
+        const float fx = stx[qi * RD + a0];
+        const int py = ymask[qi] >> 16;
+        const float* tcol = tile + qi * G::STQ + sjx[qi * RD + a0] + py * TW;
+        float h[RD + 3];                                      // tile rows py - 1 .. py + RD + 1
+        {
+            const float* r0 = py ? tcol - TW : tcol;          // row above the tile: weight zero, any finite value
+            h[0] = r0[0] + fx * (r0[1] - r0[0]);
+        }
 #pragma unroll
-        for (int k = 0; k <= RD; ++k) { c0[k] = tq[k * TW + a0]; c1[k] = tq[k * TW + a0 + 1]; }
+        for (int k = 1; k < RD + 3; ++k) {
+            const float* rk = tcol + (k - 1) * TW;
+            h[k] = rk[0] + fx * (rk[1] - rk[0]);
+        }
         float ex[NEX > 0 ? NEX : 1];
 #pragma unroll
-        for (int i = 0; i < NEX; ++i) {
-            const int a = NCOL + i / ((RD + 7) / 8), bb = min(g8 + 8 * (i % ((RD + 7) / 8)), RD - 1);
-            const float* tp = tq + bb * TW + a;
-            ex[i] = tp[0] * w00 + tp[1] * w01 + tp[TW] * w10 + tp[TW + 1] * w11;
-        }
+        for (int i = 0; i < NEX; ++i)
+            ex[i] = sample(qi, NCOL + i / ((RD + TPQ - 1) / TPQ), min(g8 + TPQ * (i % ((RD + TPQ - 1) / TPQ)), RD - 1));
+        float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
         auto emit = [&](int ch, float v) {
             if (xsink) xsink[(l * rd2 + ch) * XS + qi] = vq ? v : 0.f;
             else if (vq) __builtin_nontemporal_store(v, &out[(size_t)ch * N + qi]);
         };
         if (g8 < NCOL) {
 #pragma unroll
-            for (int bb = 0; bb < RD; ++bb)
-                emit(g8 * RD + bb, c0[bb] * w00 + c1[bb] * w01 + c0[bb + 1] * w10 + c1[bb + 1] * w11);
+            for (int bb = 0; bb < RD; ++bb) {
+                const float4 w = wy[qi * RD + bb];
+                emit(g8 * RD + bb, w.x * h[bb] + w.y * h[bb + 1] + w.z * h[bb + 2] + w.w * h[bb + 3]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NEX; ++i) {
-            const int a = NCOL + i / ((RD + 7) / 8), bb = g8 + 8 * (i % ((RD + 7) / 8));
+            const int a = NCOL + i / ((RD + TPQ - 1) / TPQ), bb = g8 + TPQ * (i % ((RD + TPQ - 1) / TPQ));
             if (bb < RD) emit(a * RD + bb, ex[i]);
         }
     }
     RC_STAMP(3);
 }
 
-template <int R, int KIND>
+template <int R, int KIND, int NT>
 __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem)
 {
     const int r = (R >= 0) ? R : p.r;
@@ -389,6 +494,10 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
     const int ST = TT | 1;                       // odd stride: conflict-free query-major reads
     const LookupSmem s = carve(smem, r, false);
     float* taps = s.tile;
+    int* sjx = s.ytab + QB * T;                  // [QB][rd] low tap of window column a (window-relative)
+    int* sjy = sjx + QB * rd;
+    float* stx = (float*)(sjy + QB * rd);        // [QB][rd] fraction of window column a
+    float* sty = stx + QB * rd;
 
     const int l = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QB;
@@ -398,17 +507,35 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
     const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
 
     RC_STAMP(0);
-    build_tables<R, KIND>(p, s, g, b, q0, l, r);
+    build_tables<R, KIND, NT>(p, s, g, b, q0, l, r);
+    {   // per-sample (low tap, fraction): where the reference samples (ref_sample_tap)
+        const bool fork = p.mode == RAFTCORR_MODE_FORK;
+        const float cscale = fork ? 1.0f : 1.0f / (float)(1 << l);
+        for (int e = tid; e < 2 * QB * rd; e += NT) {
+            const bool isy = e >= QB * rd;
+            const int ee = isy ? e - QB * rd : e;
+            const int qi = ee / rd, a = ee - qi * rd;
+            const int q = min(q0 + qi, N - 1);
+            const size_t idx = fork ? ((size_t)b * N + q) * 2 + (isy ? 1 : 0)
+                                    : ((size_t)b * 2 + (isy ? 1 : 0)) * N + q;
+            const float c = p.coords[idx] * cscale;
+            int c0; float fc;
+            split_coord(c, c0, fc);
+            int j; float t;
+            ref_sample_tap(c, c0 > -(1 << 23), a, r, isy ? g.h : g.w, isy ? p.rcp_h[l] : p.rcp_w[l], c0 - r, a, fc, T - 2, j, t);
+            if (isy) { sjy[ee] = j; sty[ee] = t; } else { sjx[ee] = j; stx[ee] = t; }
+        }
+    }
     __syncthreads();
     RC_STAMP(1);
 
     if (R >= 0) {
         constexpr int Rc = R >= 0 ? R : 0;
         constexpr int Tc = 2 * Rc + 2, TTc = Tc * Tc;
-        constexpr int NIT = (QB * TTc + 255) / 256;
+        constexpr int NIT = (QB * TTc + NT - 1) / NT;
         float v[NIT];
         int off[NIT];
-        int qi = tid / TTc, t = tid - qi * TTc;   // tap e = tid + 256*i, walked incrementally
+        int qi = tid / TTc, t = tid - qi * TTc;   // tap e = tid + NT*i, walked incrementally
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int qc = min(qi, QB - 1);
@@ -416,18 +543,18 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
             const int o = s.ytab[qc * Tc + ty] + s.xtab[qc * Tc + tx];
             off[i] = (qi < QB && o >= 0) ? o : -1;
             v[i] = vol[max(o, 0)];                // invalid taps read a valid dummy address
-            t += 256 % TTc; qi += 256 / TTc;
+            t += NT % TTc; qi += NT / TTc;
             if (t >= TTc) { t -= TTc; ++qi; }
         }
         qi = tid / TTc; t = tid - qi * TTc;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (qi < QB) taps[qi * ST + t] = off[i] >= 0 ? v[i] : 0.f;
-            t += 256 % TTc; qi += 256 / TTc;
+            t += NT % TTc; qi += NT / TTc;
             if (t >= TTc) { t -= TTc; ++qi; }
         }
     } else {
-        for (int e = tid; e < QB * TT; e += 256) {
+        for (int e = tid; e < QB * TT; e += NT) {
             const int qi = e / TT;
             const int t = e - qi * TT;
             const int ty = t / T, tx = t - ty * T;
@@ -439,84 +566,68 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
     RC_STAMP(2);
 
     const int C = p.L * rd2;
+    auto sample = [&](int qi, int a, int bb) -> float {
+        const float fx = stx[qi * rd + a], fy = sty[qi * rd + bb];
+        const float* tp = taps + qi * ST + sjy[qi * rd + bb] * T + sjx[qi * rd + a];
+        return (tp[0] * (1.f - fx) + tp[1] * fx) * (1.f - fy) + (tp[T] * (1.f - fx) + tp[T + 1] * fx) * fy;
+    };
     if (p.mode == RAFTCORR_MODE_FORK) {
         // out (B, N, C): lanes run along the channel dim
         float* __restrict__ out = p.out + ((size_t)b * N + q0) * C + l * rd2;
-        for (int e = tid; e < QB * rd2; e += 256) {
+        for (int e = tid; e < QB * rd2; e += NT) {
             const int qi = e / rd2;
             const int ch = e - qi * rd2;
             const int a = ch / rd;
-            const int bb = ch - a * rd;
             if (q0 + qi >= N) break;
-            const float fx = s.sfx[qi], fy = s.sfy[qi];
-            const float* tp = taps + qi * ST + bb * T + a;
-            const float o = tp[0] * ((1.f - fx) * (1.f - fy)) + tp[1] * (fx * (1.f - fy)) +
-                            tp[T] * ((1.f - fx) * fy) + tp[T + 1] * (fx * fy);
-            __builtin_nontemporal_store(o, &out[(size_t)qi * C + ch]);
+            __builtin_nontemporal_store(sample(qi, a, ch - a * rd), &out[(size_t)qi * C + ch]);
         }
     } else {
         // out (B, C, N): lanes run along the query dim
         float* __restrict__ out = p.out + ((size_t)b * C + l * rd2) * N + q0;
         const int qi = tid & (QB - 1);
         const bool vq = q0 + qi < N;
-        const float fx = s.sfx[qi], fy = s.sfy[qi];
-        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
-        const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-        const float* tq = taps + qi * ST;
-        if (R >= 0) {
-            constexpr int Rc = R >= 0 ? R : 0;
-            constexpr int rdc = 2 * Rc + 1, Tc = 2 * Rc + 2;
-            constexpr int NOUT = (rdc * rdc + 7) / 8;
-            float o[NOUT];
-#pragma unroll
-            for (int i = 0; i < NOUT; ++i) {      // all LDS reads of the thread in flight together
-                const int ch = min(tid / QB + i * 8, rdc * rdc - 1);
-                const int a = ch / rdc, bb = ch - a * rdc;
-                const float* tp = tq + bb * Tc + a;
-                o[i] = tp[0] * w00 + tp[1] * w01 + tp[Tc] * w10 + tp[Tc + 1] * w11;
-            }
-#pragma unroll
-            for (int i = 0; i < NOUT; ++i) {
-                const int ch = tid / QB + i * 8;
-                if (vq && ch < rdc * rdc) __builtin_nontemporal_store(o[i], &out[(size_t)ch * N + qi]);
-            }
-        } else {
-            for (int ch = tid / QB; ch < rd2; ch += 256 / QB) {
-                const int a = ch / rd;
-                const int bb = ch - a * rd;
-                const float* tp = tq + bb * T + a;
-                const float o = tp[0] * w00 + tp[1] * w01 + tp[T] * w10 + tp[T + 1] * w11;
-                if (vq) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]);
-            }
+        for (int ch = tid / QB; ch < rd2; ch += NT / QB) {
+            const int a = ch / rd;
+            const float o = sample(qi, a, ch - a * rd);
+            if (vq) __builtin_nontemporal_store(o, &out[(size_t)ch * N + qi]);
         }
     }
     RC_STAMP(3);
 }
 
+// threads per block of the forward kernel: one per (query, window column) for the specialised radii
 template <int R>
-__global__ __launch_bounds__(256)
+#if defined(RC_LAB_E3)
+struct FwdThreads { static constexpr int NT = 256; };
+#else
+struct FwdThreads { static constexpr int NT = R >= 0 ? QB * (2 * R + 1) : 256; };
+#endif
+
+template <int R>
+__global__ __launch_bounds__(FwdThreads<R>::NT)
 void corr_lookup_fwd_kernel(LookupArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = FwdThreads<R>::NT;
     // level l < 4 has layout kind l, deeper levels are row-major (layout.h): the level index alone
     // selects the code path and, as a literal, makes the level's geometry a fixed kernarg offset --
     // no dependent scalar load in front of the first vector instruction
     const int kind = min((int)blockIdx.y, 4);    // block-uniform
     if constexpr (R >= 0) {
         switch (kind) {
-        case 0: lookup_fwd_blocks<R, 0>(p, smem, 0, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 1: lookup_fwd_blocks<R, 1>(p, smem, 1, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 2: lookup_fwd_blocks<R, 2>(p, smem, 2, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 3: lookup_fwd_blocks<R, 3>(p, smem, 3, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        default: lookup_fwd_body<R, 4>(p, smem); return;
+        case 0: lookup_fwd_blocks<R, 0, NT>(p, smem, 0, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 1: lookup_fwd_blocks<R, 1, NT>(p, smem, 1, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 2: lookup_fwd_blocks<R, 2, NT>(p, smem, 2, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 3: lookup_fwd_blocks<R, 3, NT>(p, smem, 3, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        default: lookup_fwd_body<R, 4, NT>(p, smem); return;
         }
     } else {
         switch (kind) {
-        case 0: lookup_fwd_body<R, 0>(p, smem); break;
-        case 1: lookup_fwd_body<R, 1>(p, smem); break;
-        case 2: lookup_fwd_body<R, 2>(p, smem); break;
-        case 3: lookup_fwd_body<R, 3>(p, smem); break;
-        default: lookup_fwd_body<R, 4>(p, smem); break;
+        case 0: lookup_fwd_body<R, 0, NT>(p, smem); break;
+        case 1: lookup_fwd_body<R, 1, NT>(p, smem); break;
+        case 2: lookup_fwd_body<R, 2, NT>(p, smem); break;
+        case 3: lookup_fwd_body<R, 3, NT>(p, smem); break;
+        default: lookup_fwd_body<R, 4, NT>(p, smem); break;
         }
     }
 }
@@ -763,7 +874,7 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef BlockGeom<R> G;
-    constexpr int GF = QB * G::STQ + 2 * QB * G::NB + 5 * QB;       // floats per level group
+    constexpr int GF = G::SMEM;                                      // floats per level group
     constexpr int GFA = (GF + 3) & ~3;
     // LDS: region A = the four level groups' tables and tap tiles, later the bf16 pieces of X;
     //      region B = X in fp32 as the lookups leave it ([k][query]), later the partial sums.
@@ -776,10 +887,10 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
     float* gs = smem + grp * GFA;
     if (grp < p.L) {
         switch (grp) {                                               // level l < 4 has layout kind l
-        case 0: lookup_fwd_blocks<R, 0>(p, gs, 0, b, q0, tid, X32); break;
-        case 1: lookup_fwd_blocks<R, 1>(p, gs, 1, b, q0, tid, X32); break;
-        case 2: lookup_fwd_blocks<R, 2>(p, gs, 2, b, q0, tid, X32); break;
-        default: lookup_fwd_blocks<R, 3>(p, gs, 3, b, q0, tid, X32); break;
+        case 0: lookup_fwd_blocks<R, 0, 256>(p, gs, 0, b, q0, tid, X32); break;
+        case 1: lookup_fwd_blocks<R, 1, 256>(p, gs, 1, b, q0, tid, X32); break;
+        case 2: lookup_fwd_blocks<R, 2, 256>(p, gs, 2, b, q0, tid, X32); break;
+        default: lookup_fwd_blocks<R, 3, 256>(p, gs, 3, b, q0, tid, X32); break;
         }
     } else {
         __syncthreads();                                             // the two barriers of lookup_fwd_blocks
@@ -805,7 +916,8 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     const int nsplit = max(1, min(16 / tiles, ks));                  // tiles * nsplit <= 16 slabs (host sizes region B for it)
     const int kper = (ks + nsplit - 1) / nsplit;
-    float* red = X32;                                                // [nsplit][tiles * 32][XS] partial sums
+    // partial sums [nsplit][tiles * 32][XS]: behind the bf16 pieces (the level groups' tiles and X32 are dead by now)
+    float* red = smem + ((3 * QB * xkp / 2 + 3) & ~3);
     for (int pr = wave; pr < tiles * nsplit; pr += 16) {
         const int mt = pr % tiles, sp = pr / tiles;
         const int s0 = sp * kper, s1 = min(ks, s0 + kper);
@@ -859,6 +971,13 @@ void corr_lookup_conv1x1_kernel(LookupArgs p, ConvArgs cv)
     }
 }
 
+// host mirror of BlockGeom<R>::SMEM
+static size_t fwd_blocks_smem_floats(int r)
+{
+    const int T = 2 * r + 2, NB = T / 2 + 1, TW = 2 * NB, rd = 2 * r + 1;
+    return (size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 2 * QB + 6 * (size_t)QB * rd;
+}
+
 size_t conv1x1_packed_bytes(int Cout, int Cin)
 {
     return sizeof(uint4) * (size_t)((Cout + 31) / 32) * conv_ksteps(Cin) * 3 * 64;
@@ -881,16 +1000,18 @@ int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r,
     LookupArgs a = {};
     a.lv = lv; a.coords = coords; a.out = nullptr;
     a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = RAFTCORR_MODE_CANONICAL;
+    set_reciprocals(a);
     const int rd = 2 * r + 1;
     ConvArgs c = {(const uint4*)wpacked, bias, out, L * rd * rd, Cout, relu};
-    const int T = 2 * r + 2, NB = T / 2 + 1, TW = 2 * NB;
-    const size_t gf = ((size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 5 * QB + 3) & ~(size_t)3;
+    const size_t gf = (fwd_blocks_smem_floats(r) + 3) & ~(size_t)3;
     const int tiles = (Cout + 31) / 32;
-    const size_t regA = std::max(sizeof(float) * 4 * gf, sizeof(unsigned short) * 3 * QB * (size_t)conv_xkp(c.Cin));
-    const size_t regB = sizeof(float) * XS * std::max<size_t>((size_t)c.Cin, (size_t)std::max(tiles, 16 / std::max(tiles, 1) * tiles) * 32);
-    // the kernel places region B at 4 * gf floats: region A must not be larger than that
-    if (regA > sizeof(float) * 4 * gf) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: Cin = %d too large", c.Cin);
-    const size_t sm = regA + regB;
+    // LDS: [4 level groups | X32 (fp32 lookup results)] during the lookups, then
+    //      [bf16 pieces of X | partial sums] during the product
+    const size_t pieces = sizeof(float) * ((3 * QB * (size_t)conv_xkp(c.Cin) / 2 + 3) & ~(size_t)3);
+    const size_t red = sizeof(float) * XS * (size_t)std::max(tiles, 16 / std::max(tiles, 1) * tiles) * 32;
+    // the kernel places X32 at 4 * gf floats: the pieces (written while X32 is read) must end before it
+    if (pieces > sizeof(float) * 4 * gf) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: Cin = %d too large", c.Cin);
+    const size_t sm = std::max(sizeof(float) * (4 * gf + (size_t)XS * c.Cin), pieces + red);
     if (sm > 160 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_conv1x1: needs %zu bytes of LDS", sm);
     dim3 grid((a.N + QB - 1) / QB, 1, B), block(1024);
     // more than 64 KiB of dynamic LDS needs opting in, once per kernel and device context
@@ -920,8 +1041,8 @@ static size_t lookup_smem(int r, bool bwd)
     const int stride = bwd ? ((rd * rd) | 1) : ((T * T) | 1);
     size_t fl = (size_t)QB * stride + 2 * QB + 2 * QB * T;
     if (!bwd) {                                   // block-load path (compile-time radius)
-        const int NB = T / 2 + 1, TW = 2 * NB;
-        const size_t f4 = (size_t)QB * ((TW * TW) | 1) + 2 * QB * NB + 5 * QB;
+        fl += 4 * (size_t)QB * rd;                // per-sample (tap, fraction) tables of the generic path
+        const size_t f4 = fwd_blocks_smem_floats(r);
         if (f4 > fl) fl = f4;
     }
     return sizeof(float) * fl;
@@ -933,12 +1054,13 @@ int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, con
     LookupArgs a = {};
     a.lv = lv; a.coords = coords; a.out = out;
     a.B = B; a.N = H * W; a.L = L; a.r = r; a.mode = mode;
+    set_reciprocals(a);
     const size_t sm = lookup_smem(r, false);
     if (sm > 64 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_fwd: radius %d too large", r);
-    dim3 grid((a.N + QB - 1) / QB, L, B), block(256);
-    if (r == 4)      hipLaunchKernelGGL(corr_lookup_fwd_kernel<4>, grid, block, sm, s, a);
-    else if (r == 3) hipLaunchKernelGGL(corr_lookup_fwd_kernel<3>, grid, block, sm, s, a);
-    else             hipLaunchKernelGGL(corr_lookup_fwd_kernel<-1>, grid, block, sm, s, a);
+    dim3 grid((a.N + QB - 1) / QB, L, B);
+    if (r == 4)      hipLaunchKernelGGL(corr_lookup_fwd_kernel<4>, grid, dim3(FwdThreads<4>::NT), sm, s, a);
+    else if (r == 3) hipLaunchKernelGGL(corr_lookup_fwd_kernel<3>, grid, dim3(FwdThreads<3>::NT), sm, s, a);
+    else             hipLaunchKernelGGL(corr_lookup_fwd_kernel<-1>, grid, dim3(256), sm, s, a);
     return check_launch("corr_lookup_fwd_kernel");
 }
 
