@@ -123,7 +123,7 @@ constexpr int TAB_INVALID = -(1 << 30);    // marks a window row / column outsid
 //     n = 2 p / (dim - 1);  g = n - 1;  ix = (g + 1) * ((dim - 1) / 2)        (each step rounded to fp32)
 // ((dim-1)/2 is exact, so ATen's CPU form above and its CUDA form ((g+1)/2)*(dim-1) round identically.)
 // The round trip moves a sample by O(1e-7 * dim) pixels -- 2e-6 of max|out| at W = 40, but 1e-5 at
-// W = 240 (fixtures K1 / P1, tests/test_oracle_golden.py) -- and differently for each of the 2r+1
+// W = 240 (fixtures K1 / P1 under tests/golden) -- and differently for each of the 2r+1
 // window offsets: the samples of a window do not share one fractional offset exactly.  This returns
 // ix for window offset `a`, every step one correctly rounded fp32 operation (contraction off), i.e.
 // bit for bit the reference's.  The division uses the host's correctly rounded reciprocal rcp =
