@@ -397,7 +397,8 @@ def extras_kitti(torch, wl, dev):
     out = {}
     with torch.no_grad():
         blk = AlternateCorrBlock(wl.f1.detach(), wl.f2.detach(), num_levels=LEVELS, radius=RADIUS)
-        f1n, f2n = blk._f1, blk._f2
+        f1n = blk.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
+        f2n = [blk.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(LEVELS)]
         gout = wl.gouts[0]
         d1 = torch.empty_like(f1n)
         d2 = [torch.zeros_like(t) for t in f2n]
@@ -405,8 +406,9 @@ def extras_kitti(torch, wl, dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         o = torch.empty(B, LEVELS * 81, H, W, device=dev)
         for tag, c in (("identity", wl.coords[0]), ("sigma3", wl.coords[1]), ("sigma6", wl.coords[4])):
-            tf = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd(f1n.data_ptr(), lv, B, H, W, D, LEVELS, RADIUS,
-                                                                      c.data_ptr(), o.data_ptr(), stream))
+            tf = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(),
+                                                                      B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
+                                                                      stream))
             tb = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(f1n.data_ptr(), lv, B, H, W, D, LEVELS, RADIUS,
                                                                       c.data_ptr(), gout.data_ptr(), d1.data_ptr(), dlv,
                                                                       stream))

@@ -182,17 +182,35 @@ int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* c
                           int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
                           void* stream);
 
-/* Replaces AlternateCorrBlock.__call__ (core/corr.py:75-92) in ONE launch: all levels, the
- * per-level coords/2**l, the stack/reshape and the 1/sqrt(C) scale fused.
- * fmap1 (B,H,W,C) NHWC; fmap2_levels: HOST array of DEVICE pointers, level l = avg-pooled
- * fmap2 (B,H_l,W_l,C) NHWC; coords (B,2,H,W); out (B, L*rd*rd, H, W), overwritten. */
-int raftcorr_alt_lookup_fwd(const float* fmap1, const float* const* fmap2_levels,
+/* Replaces AlternateCorrBlock (core/corr.py:64-92) for the per-iteration call: all levels, the per-level
+ * coords/2**l, the stack/reshape and the 1/sqrt(C) scale in ONE launch, on the 16-bit matrix cores at
+ * fp32-grade accuracy.  The features are packed ONCE per frame pair (the constructor's job, as the
+ * reference builds its feature pyramid once, corr.py:69-73; it re-permutes the maps on every call, :83-84):
+ *   raftcorr_alt_scales   partial maxima of |fmap1| and |fmap2| -> scales (2 x 128 floats, device memory);
+ *                         every map is scaled by a power of two into the top of fp16's range
+ *   raftcorr_alt_pack     one map (B,C,H,W) float32 NCHW -> packed: per pixel and 32-channel chunk one
+ *                         128-byte line of two fp16 pieces per value (x = hi + lo, 22 significand bits);
+ *                         scale: the 128 partial maxima of THAT map's family (scales for fmap1,
+ *                         scales + 128 for fmap2 and all of its avg-pooled levels, whose maxima are no larger);
+ *                         packed: raftcorr_alt_packed_bytes(B, C, H, W) bytes, caller-allocated
+ *   raftcorr_alt_lookup_fwd   packed1: fmap1; packed2_levels: HOST array of DEVICE pointers, level l = packed
+ *                         F.avg_pool2d chain of fmap2 ((B,C,H>>l,W>>l)); coords (B,2,H,W); out (B, L*rd*rd, H, W),
+ *                         overwritten.  Values: the reference's sum of products in fp32-grade arithmetic
+ *                         (three fp16 MFMA terms hi*hi + hi*lo + lo*hi, fp32 accumulation, exact unscale),
+ *                         then / sqrt(C) as corr.py:92. */
+int64_t raftcorr_alt_packed_bytes(int B, int C, int H, int W);
+int raftcorr_alt_scales(const float* fmap1, const float* fmap2, int B, int C, int H, int W, float* scales, void* stream);
+int raftcorr_alt_pack(const float* fmap, int B, int C, int H, int W, const float* scale, void* packed,
+                      int64_t packed_bytes, void* stream);
+int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_levels, const float* scales,
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, float* out, void* stream);
 
-/* Backward of raftcorr_alt_lookup_fwd.  dfmap1 (B,H,W,C) is overwritten (in-wave reduction,
- * no atomics); dfmap2_levels[l] (B,H_l,W_l,C) must be zeroed by the caller and is accumulated
- * with float atomics (targets collide across queries). */
+/* Backward of raftcorr_alt_lookup_fwd w.r.t. the features (the reference exports corr_backward,
+ * correlation.cpp:36-48, but never wires it into autograd).  fmap1 (B,H,W,C) and fmap2_levels[l]
+ * (B,H_l,W_l,C): float32 NHWC as the reference kernel takes them (correlation_kernel.cu:22-24).
+ * dfmap1 (B,H,W,C) is zeroed and accumulated here; dfmap2_levels[l] (B,H_l,W_l,C) must be zeroed by the
+ * caller and is accumulated with float atomics (targets collide across queries). */
 int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels,
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, const float* dout,

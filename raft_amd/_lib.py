@@ -49,7 +49,10 @@ _SIGNATURES = {
                             ctypes.c_void_p], _c_int),
     "raftcorr_alt_forward": ([_c_fp, _c_fp, _c_fp, _c_fp] + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
     "raftcorr_alt_backward": ([_c_fp] * 7 + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
-    "raftcorr_alt_lookup_fwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 6 +
+    "raftcorr_alt_packed_bytes": ([_c_int] * 4, ctypes.c_int64),
+    "raftcorr_alt_scales": ([_c_fp, _c_fp] + [_c_int] * 4 + [_c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_alt_pack": ([_c_fp] + [_c_int] * 4 + [_c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
+    "raftcorr_alt_lookup_fwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
                                 [_c_fp, _c_fp, ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_bwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 6 +
                                 [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],

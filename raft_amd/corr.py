@@ -418,23 +418,28 @@ def _pack_conv_weight(lib, weight, cout, cin):
     return packed
 
 
+def _alt_forward(blk, coords):
+    """raftcorr_alt_lookup_fwd on the block's packed features (all levels, one launch)."""
+    lib = _lib.load()
+    B, C, H, W = blk._shape
+    L = blk.num_levels
+    out = torch.empty(B, L * (2 * blk.radius + 1) ** 2, H, W, dtype=torch.float32, device=coords.device)
+    with _guard(coords):
+        _lib.check(lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
+                                               blk.radius, coords.data_ptr(), out.data_ptr(), _stream(coords)),
+                   "alt_lookup_fwd")
+    return out
+
+
 class _AltLookup(torch.autograd.Function):
-    """All levels of the on-the-fly correlation in one launch (forward) / one launch (backward)."""
+    """All levels of the on-the-fly correlation in one launch (forward); backward w.r.t. the features
+    from their float32 NHWC copies (the layout of the reference kernel, correlation_kernel.cu:22-24)."""
 
     @staticmethod
-    def forward(ctx, coords, radius, fmap1, *fmap2_levels):
-        lib = _lib.load()
-        B, H, W, C = fmap1.shape
-        L = len(fmap2_levels)
-        rd2 = (2 * radius + 1) ** 2
-        out = torch.empty(B, L * rd2, H, W, dtype=torch.float32, device=fmap1.device)
-        with _guard(fmap1):
-            _lib.check(lib.raftcorr_alt_lookup_fwd(fmap1.data_ptr(), _lib.ptr_array(fmap2_levels), B, H, W,
-                                                   C, L, radius, coords.data_ptr(), out.data_ptr(),
-                                                   _stream(fmap1)), "alt_lookup_fwd")
-        ctx.radius = radius
+    def forward(ctx, coords, blk, fmap1, *fmap2_levels):
+        ctx.radius = blk.radius
         ctx.save_for_backward(coords, fmap1, *fmap2_levels)
-        return out
+        return _alt_forward(blk, coords)
 
     @staticmethod
     @once_differentiable
@@ -457,7 +462,12 @@ class _AltLookup(torch.autograd.Function):
 
 class AlternateCorrBlock:
     """Memory-lean on-the-fly correlation.  Drop-in for core/corr.py:64-92 (defaults
-    num_levels=4, radius=4); unlike the reference it is differentiable w.r.t. the features."""
+    num_levels=4, radius=4); unlike the reference it is differentiable w.r.t. the features.
+
+    The constructor packs the features once per frame pair for the 16-bit matrix cores (two fp16
+    pieces per value, fp32-grade products: include/raftcorr.h); every call is then ONE launch for all
+    levels.  float32 NHWC copies (what the backward kernels read) are made only when a gradient can
+    flow to the features."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         self.num_levels = num_levels
@@ -470,21 +480,52 @@ class AlternateCorrBlock:
             raise RuntimeError(f"AlternateCorrBlock: num_levels must be in [1, {_lib.MAX_LEVELS}]")
         if radius < 0:
             raise RuntimeError("AlternateCorrBlock: radius must be >= 0")
+        if radius > 7:
+            raise RuntimeError("AlternateCorrBlock: radius > 7 is not built")
         fmap1, fmap2 = fmap1.float(), fmap2.float()
+        B, C, H, W = fmap1.shape
+        if (H >> (num_levels - 1)) < 1 or (W >> (num_levels - 1)) < 1:
+            raise RuntimeError(f"AlternateCorrBlock: a {H} x {W} map has no level {num_levels - 1}: output size is too small")
         self.pyramid = [(fmap1, fmap2)]                        # core/corr.py:69-73 (L+1 entries)
         for _ in range(self.num_levels):
-            fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
-            fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
+            fmap1 = F.avg_pool2d(fmap1, 2, stride=2) if min(fmap1.shape[-2:]) >= 2 else fmap1[..., :0, :0]
+            fmap2 = F.avg_pool2d(fmap2, 2, stride=2) if min(fmap2.shape[-2:]) >= 2 else fmap2[..., :0, :0]
             self.pyramid.append((fmap1, fmap2))
-        # NHWC copies made once here (the reference re-makes them on every call, corr.py:83-84)
-        self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
-        self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+        self._shape = (B, C, H, W)
+        lib = _lib.load()
+        f1 = self.pyramid[0][0].detach().contiguous()
+        f2 = [self.pyramid[i][1].detach().contiguous() for i in range(num_levels)]
+        dev = f1.device
+        self._scales = torch.empty(256, dtype=torch.float32, device=dev)      # partial maxima of |fmap1|, |fmap2|
+        with _guard(f1):
+            st = _stream(f1)
+            _lib.check(lib.raftcorr_alt_scales(f1.data_ptr(), f2[0].data_ptr(), B, C, H, W, self._scales.data_ptr(), st),
+                       "alt_scales")
+
+            def pack(t, scale_ptr):
+                b, c, h, w = t.shape
+                nbytes = lib.raftcorr_alt_packed_bytes(b, c, h, w)
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.raftcorr_alt_pack(t.data_ptr(), b, c, h, w, scale_ptr, buf.data_ptr(), nbytes, st), "alt_pack")
+                return buf
+
+            self._p1 = pack(f1, self._scales.data_ptr())
+            self._p2 = [pack(t, self._scales.data_ptr() + 128 * 4) for t in f2]
+        self._p2ptrs = _lib.ptr_array(self._p2)
+        self._grad = torch.is_grad_enabled() and (self.pyramid[0][0].requires_grad or self.pyramid[0][1].requires_grad)
+        self._f1 = self._f2 = None                              # float32 NHWC copies, for the backward pass only
+        if self._grad:
+            self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
+            self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
 
     def __call__(self, coords):
         _require_cuda(coords=coords)
-        if coords.device != self._f1.device:
-            raise RuntimeError(f"coords is on {coords.device}, the feature maps on {self._f1.device}")
-        B, H, W, C = self._f1.shape
+        if coords.device != self._p1.device:
+            raise RuntimeError(f"coords is on {coords.device}, the feature maps on {self._p1.device}")
+        B, C, H, W = self._shape
         if coords.shape != (B, 2, H, W):
             raise RuntimeError(f"AlternateCorrBlock: coords must be ({B}, 2, {H}, {W}); got {tuple(coords.shape)}")
-        return _AltLookup.apply(_f32c(coords).detach(), self.radius, self._f1, *self._f2)
+        coords = _f32c(coords).detach()
+        if self._grad and torch.is_grad_enabled():
+            return _AltLookup.apply(coords, self, self._f1, *self._f2)
+        return _alt_forward(self, coords)

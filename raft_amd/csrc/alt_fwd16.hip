@@ -1,0 +1,386 @@
+// On-the-fly ("alternate") correlation, forward, on the 16-bit matrix cores at fp32-grade accuracy.
+// Replaces AlternateCorrBlock.__call__ (core/corr.py:75-92: per level permute + alt_cuda_corr.forward
+// (correlation_kernel.cu:19-119) + stack + / sqrt(C)) in one launch for all levels.
+//
+// Same idea as alt_tile.hip (the fp32-MFMA version, which still serves the pybind drop-in): neighbouring
+// queries look at overlapping windows, so a workgroup takes a TILE of queries, finds the bounding box of
+// their windows at one level and computes the dense product  S[q][u] = <f1[q], f2_l[u]>  on the matrix
+// cores; every query then picks its (2r+2)^2 taps out of S in LDS and blends them.  What is new:
+//
+//  * 8x8 = 64 queries per workgroup (two MFMA row blocks share every staged target), box walked in passes
+//    of 256 targets (8 MFMA column blocks); a pass computes only the column blocks that hold box targets.
+//  * The features are PACKED once per frame pair (raftcorr_alt_pack, the constructor of AlternateCorrBlock):
+//    each map is scaled by a power of two into the top of fp16's range and every value split into two fp16
+//    pieces x = hi + lo (22 significand bits).  The product is three v_mfma_f32_32x32x16_f16 terms
+//    (hi*hi + hi*lo + lo*hi) accumulated in fp32 and unscaled exactly -- the fp16x2 scheme of
+//    build_pyramid.hip, fp32-grade (2e-7 of max|S| at C = 256) at 16/3 of the fp32 MFMA rate.
+//  * Packed layout: per pixel, per 32-channel chunk, one 128-byte line [piece][k-step][k-half][8 x fp16] --
+//    an MFMA operand fragment is one 16-byte slot.  Target lines go global -> LDS by direct-to-LDS DMA
+//    (global_load_lds_dwordx4, 8 lanes per line, no VGPR round trip, no conversion), double buffered, one
+//    barrier per chunk; slots are XOR-swizzled by (row >> 1) & 7 on the way in (the DMA writes 1 KiB
+//    contiguously, the swizzle is applied to the SOURCE slot each lane fetches) so that the ds_read_b128
+//    fragment reads of 128-byte rows are bank-conflict-free.  A wave's query fragments are private to it
+//    and are read straight from global memory one chunk ahead.
+#include "common.h"
+#include <limits.h>
+#include <algorithm>
+
+namespace raftcorr {
+
+namespace {
+
+constexpr int QW = 8, QH = 8, TQ = QW * QH;       // query tile
+constexpr int UP = 256;                           // box targets per pass (8 MFMA column blocks)
+constexpr int KC = 32;                            // channels per staged chunk = one 128-byte line per pixel
+constexpr int LDS_S = UP + 1;                     // S[q][u] row stride (odd: the per-query gathers are conflict-free)
+constexpr int MAXPARTS16 = 128;                   // partial maxima per map (corr_maxabs_kernel, build_pyramid.hip)
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct AltFwdArgs {
+    const uint4* f1p;                             // packed fmap1: [B][H*W][Cp/32][8 slots of 16 B]
+    const uint4* f2p[RAFTCORR_MAX_LEVELS];        // packed pooled fmap2, level l: [B][H_l*W_l][Cp/32][8]
+    int hl[RAFTCORR_MAX_LEVELS], wl[RAFTCORR_MAX_LEVELS];
+    const float* coords;                          // (B, 2, H, W)
+    float* out;                                   // (B, L*rd*rd, H, W)
+    const float* maxpart;                         // [2][MAXPARTS16]: partial maxima of |fmap1|, |fmap2| (scales)
+    int B, C, Cp, H, W, L, r;
+    int band;                                     // tiles per XCD band
+    float sqrt_c;
+};
+
+struct TileSh {
+    int wx0[TQ], wy0[TQ];                         // window origin (x0 - r, y0 - r) per query
+    float fx[TQ], fy[TQ];
+    int qpix[TQ];                                 // query pixel index, -1 outside the map
+    int box[4];
+    int toff[UP];                                 // pixel index of the pass' box targets in the level, -1 beyond the box
+};
+
+__device__ __forceinline__ float wave_max128(const float* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    float m = fmaxf(part[lane], part[lane + 64]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+// power-of-two factor that maps max|x| into [2^14, 2^15) (as build_pyramid.hip:range_exponent)
+__device__ __forceinline__ int range_exp16(float m)
+{
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);
+    return 15 - e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack: (B, C, HW) fp32 NCHW -> [B][HW][Cp/32][piece 2][32 ch] fp16, scaled.  grid (ceil(HW/256), Cp/8, B)
+__global__ __launch_bounds__(256)
+void alt_pack16_kernel(const float* __restrict__ f, uint4* __restrict__ packed, int C, int Cp, int HW,
+                       const float* __restrict__ maxpart)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x, c0 = blockIdx.y * 8, b = blockIdx.z;
+    const float scale = ldexpf(1.0f, range_exp16(wave_max128(maxpart)));
+    if (pix >= HW) return;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = f[((size_t)b * C + min(c0 + j, C - 1)) * HW + pix];   // all 8 loads in flight
+    unsigned short h[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = c0 + j < C ? x[j] * scale : 0.f;
+        const _Float16 hi = (_Float16)v;                     // RNE
+        const _Float16 lo = (_Float16)(v - (float)hi);       // exact remainder, rounded once
+        h[0][j] = __builtin_bit_cast(unsigned short, hi);
+        h[1][j] = __builtin_bit_cast(unsigned short, lo);
+    }
+    uint4* dst = packed + ((size_t)b * HW + pix) * (Cp / 32) * 8 + (c0 >> 5) * 8 + ((c0 & 31) >> 3);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+        uint4 w;
+        w.x = h[pc][0] | ((unsigned)h[pc][1] << 16); w.y = h[pc][2] | ((unsigned)h[pc][3] << 16);
+        w.z = h[pc][4] | ((unsigned)h[pc][5] << 16); w.w = h[pc][6] | ((unsigned)h[pc][7] << 16);
+        dst[pc * 4] = w;                                     // slot = piece * 4 + (channel % 32) / 8
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_chunk)
+{
+    // 64 lanes x 16 B: per-lane global source, LDS destination = chunk base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
+}
+
+struct Tile16 {
+    int b, l, ty0, tx0, Hl, Wl, HWl;
+    bool live;
+    int xmin, ymin, bw, bh, U;
+};
+
+// queries' window origins + the bounding box of their in-level parts (wave 0: one lane per query)
+__device__ __forceinline__ Tile16 tile_setup16(const AltFwdArgs& p, TileSh& sh)
+{
+    Tile16 t;
+    const int tiles_x = (p.W + QW - 1) / QW, tiles = tiles_x * ((p.H + QH - 1) / QH);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int j = idx % p.band, bl = idx / p.band;
+    const int tile = xcd * p.band + j;
+    t.l = bl % p.L;
+    t.b = bl / p.L;
+    t.live = tile < tiles;
+    if (!t.live) return t;                                   // whole workgroup
+    t.ty0 = (tile / tiles_x) * QH;
+    t.tx0 = (tile % tiles_x) * QW;
+    t.Hl = p.hl[t.l]; t.Wl = p.wl[t.l]; t.HWl = t.Hl * t.Wl;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int qi = tid, gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
+        const bool valid = gy < p.H && gx < p.W;
+        const int T = 2 * p.r + 2;
+        int wx0 = -(1 << 24), wy0 = -(1 << 24);
+        float fx = 0.f, fy = 0.f;
+        if (valid) {
+            const size_t P = (size_t)p.H * p.W, q = (size_t)gy * p.W + gx;
+            const float* c = p.coords + (size_t)t.b * 2 * P + q;
+            const float s = 1.0f / (float)(1 << t.l);        // exact power of two == coords / 2**l (corr.py:86)
+            int x0, y0;
+            split_coord(c[0] * s, x0, fx);
+            split_coord(c[P] * s, y0, fy);
+            wx0 = x0 - p.r; wy0 = y0 - p.r;
+        }
+        const int qx0 = max(wx0, 0), qx1 = min(wx0 + T - 1, t.Wl - 1);
+        const int qy0 = max(wy0, 0), qy1 = min(wy0 + T - 1, t.Hl - 1);
+        const bool has = valid && qx0 <= qx1 && qy0 <= qy1;
+        int mnx = has ? qx0 : INT_MAX, mxx = has ? qx1 : INT_MIN;
+        int mny = has ? qy0 : INT_MAX, mxy = has ? qy1 : INT_MIN;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, m)); mxx = max(mxx, __shfl_xor(mxx, m));
+            mny = min(mny, __shfl_xor(mny, m)); mxy = max(mxy, __shfl_xor(mxy, m));
+        }
+        sh.wx0[qi] = wx0; sh.wy0[qi] = wy0; sh.fx[qi] = fx; sh.fy[qi] = fy;
+        sh.qpix[qi] = valid ? gy * p.W + gx : -1;
+        if (tid == 0) { sh.box[0] = mnx; sh.box[1] = mxx; sh.box[2] = mny; sh.box[3] = mxy; }
+    }
+    __syncthreads();
+    const int mnx = sh.box[0], mxx = sh.box[1], mny = sh.box[2], mxy = sh.box[3];
+    if (mnx > mxx || mny > mxy) { t.xmin = 0; t.ymin = 0; t.bw = 1; t.bh = 0; t.U = 0; }
+    else { t.xmin = mnx; t.ymin = mny; t.bw = mxx - mnx + 1; t.bh = mxy - mny + 1; t.U = t.bw * t.bh; }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  grid: 8 XCD bands x (tiles per band x L x B), block 256 = 4 waves.
+// wave w: MFMA row block mb = w & 1 (32 of the 64 queries), column blocks (w >> 1) + 2 j, j = 0..3.
+// RMAX: largest radius the instantiation's register arrays hold.
+template <int RMAX>
+__global__ __launch_bounds__(256, 2)
+void alt_fwd16_kernel(AltFwdArgs p)
+{
+    constexpr int RDM = 2 * RMAX + 1, NCOL = (RDM + 3) / 4;  // window columns per thread (4 threads per query)
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];     // 2 x [UP rows][8 slots] staging; later S[TQ][LDS_S]
+    __shared__ TileSh sh;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = p.r, rd = 2 * r + 1, rd2 = rd * rd, T = 2 * r + 2;
+    const Tile16 t = tile_setup16(p, sh);
+    if (!t.live) return;
+    const int nkc = p.Cp / KC;
+    const size_t P = (size_t)p.H * p.W;
+    const int mb = wave & 1, nb0 = wave >> 1;
+
+    // this lane's A fragments (query row mb*32 + l31): slot = piece * 4 + k-step * 2 + kh of every chunk's line
+    const int myq = sh.qpix[mb * 32 + l31];
+    const uint4* __restrict__ arow = p.f1p + ((size_t)t.b * P + max(myq, 0)) * nkc * 8 + kh;
+    const uint4* __restrict__ f2b = p.f2p[t.l] + (size_t)t.b * t.HWl * nkc * 8;
+
+    // outputs of this thread: query qi = tid & 63, window columns a = g4 + 4 i (g4 = wave: uniform per wave)
+    const int qi = tid & 63, g4 = wave;
+    float o[NCOL][RDM];
+#pragma unroll
+    for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+        for (int bb = 0; bb < RDM; ++bb) o[i][bb] = 0.f;
+
+    uint4* stg0 = smem;
+    uint4* stg1 = smem + UP * 8;
+    float* S = (float*)smem;
+
+    for (int ubase = 0; ubase < t.U; ubase += UP) {
+        __syncthreads();                                     // previous pass: S and toff are no longer read
+        {
+            const int u = ubase + tid;
+            int off = -1;
+            if (u < t.U) { const int uy = u / t.bw, ux = u - uy * t.bw; off = (t.ymin + uy) * t.Wl + t.xmin + ux; }
+            sh.toff[tid] = off;
+        }
+        __syncthreads();
+        const int nlive = min(t.U - ubase, UP);
+        // DMA sources of this lane for the pass: 8 row groups of 8 targets per wave (rows (i*4 + wave)*8 + lane/8);
+        // LDS slot lane&7 of row rr receives source slot (lane&7) ^ ((rr >> 1) & 7)
+        unsigned src[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rr = (i * 4 + wave) * 8 + (lane >> 3);
+            src[i] = (unsigned)max(sh.toff[rr], 0) * (unsigned)(nkc * 8) + (unsigned)((lane & 7) ^ ((rr >> 1) & 7));
+        }
+        auto stage = [&](int kc, uint4* buf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((i * 4 + wave) * 8 < nlive)              // wave-uniform: row groups beyond the box are not fetched
+                    glds16(f2b + src[i] + kc * 8, buf + (i * 4 + wave) * 64);
+        };
+        uint4 a_nxt[4], a_cur[4];
+        auto load_a = [&](int kc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_nxt[i] = arow[kc * 8 + i * 2];       // slots kh, 2+kh (hi), 4+kh, 6+kh (lo)
+        };
+        v16f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+        // K-chunk body with restrict-qualified buffers: after inlining, the DMA destination (`nxt`) and the
+        // fragment source (`cur`) carry distinct alias scopes -- with one array and a run-time buffer index hipcc
+        // waits vmcnt(0) before the first fragment read and the next chunk's DMA no longer flies under the MFMAs
+        // (build_pyramid.hip has the same construction)
+        auto kchunk = [&](int kc, const uint4* __restrict__ cur, uint4* __restrict__ nxt) {
+            __syncthreads();                                 // chunk kc has landed (vmcnt(0) precedes the barrier) and
+                                                             // nobody reads the buffer that is restaged next
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            if (kc + 1 < nkc) { stage(kc + 1, nxt); load_a(kc + 1); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nb = nb0 + 2 * j;
+                if (nb * 32 < nlive) {                       // wave-uniform
+                    const int rr = nb * 32 + l31, key = (rr >> 1) & 7;
+                    const uint4* brow = cur + rr * 8;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint4 bh = brow[(s * 2 + kh) ^ key], bl = brow[(4 + s * 2 + kh) ^ key];
+                        const f16x8 ah = __builtin_bit_cast(f16x8, a_cur[s]), al = __builtin_bit_cast(f16x8, a_cur[2 + s]);
+                        // small terms first: lo*hi, hi*lo, hi*hi
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, bh), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bl), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bh), acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        stage(0, stg0);
+        load_a(0);
+        for (int kc = 0; kc < nkc; kc += 2) {
+            kchunk(kc, stg0, stg1);
+            if (kc + 1 < nkc) kchunk(kc + 1, stg1, stg0);
+        }
+        __syncthreads();                                     // staging buffers are free: S takes their place
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = nb0 + 2 * j;
+            if (nb * 32 < nlive) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    S[row * LDS_S + nb * 32 + l31] = acc[j][i];
+                }
+            }
+        }
+        __syncthreads();
+        // gather: window column a needs tap columns a, a+1 for the T tap rows; u = (wy+ty-ymin)*bw + (wx+tx-xmin) - ubase
+        const int wx = sh.wx0[qi] - t.xmin, wy = sh.wy0[qi] - t.ymin;
+        const float fx = sh.fx[qi], fy = sh.fy[qi];
+        const float* Sq = S + qi * LDS_S;
+#pragma unroll
+        for (int i = 0; i < NCOL; ++i) {
+            const int a = g4 + 4 * i;
+            if (a < rd) {                                    // wave-uniform
+                const int x0 = wx + a, x1 = x0 + 1;
+                const bool vx0 = (unsigned)x0 < (unsigned)t.bw, vx1 = (unsigned)x1 < (unsigned)t.bw;
+                float hprev = 0.f;
+#pragma unroll
+                for (int ty = 0; ty <= RDM; ++ty) {
+                    if (ty < T) {
+                        const int y = wy + ty;
+                        const int u = y * t.bw + x0 - ubase;
+                        const bool vy = (unsigned)y < (unsigned)t.bh;
+                        const bool ok0 = vy && vx0 && (unsigned)u < (unsigned)UP;
+                        const bool ok1 = vy && vx1 && (unsigned)(u + 1) < (unsigned)UP;
+                        const float c0 = ok0 ? Sq[max(u, 0)] : 0.f, c1 = ok1 ? Sq[max(u + 1, 0)] : 0.f;
+                        const float h = c0 * (1.f - fx) + c1 * fx;
+                        if (ty > 0) o[i][ty - 1] += hprev * (1.f - fy) + h * fy;
+                        hprev = h;
+                    }
+                }
+            }
+        }
+    }
+    const int myqi = sh.qpix[qi];
+    const float unscale = ldexpf(1.0f, -(range_exp16(wave_max128(p.maxpart)) + range_exp16(wave_max128(p.maxpart + MAXPARTS16))));
+    if (myqi >= 0) {
+        float* __restrict__ out = p.out + (((size_t)t.b * p.L + t.l) * rd2) * P + myqi;
+#pragma unroll
+        for (int i = 0; i < NCOL; ++i) {
+            const int a = g4 + 4 * i;
+            if (a < rd) {
+#pragma unroll
+                for (int bb = 0; bb < RDM; ++bb)
+                    if (bb < rd) out[(size_t)(a * rd + bb) * P] = (o[i][bb] * unscale) / p.sqrt_c;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t alt_packed_bytes(int B, int C, int H, int W)
+{
+    const size_t Cp = (size_t)(C + 31) / 32 * 32;
+    return (size_t)B * H * W * Cp * 4;
+}
+
+int launch_alt_pack(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s)
+{
+    const int Cp = (C + 31) / 32 * 32, HW = H * W;
+    hipLaunchKernelGGL(alt_pack16_kernel, dim3((HW + 255) / 256, Cp / 8, B), dim3(256), 0, s, fmap, (uint4*)packed, C, Cp, HW,
+                       maxpart);
+    return check_launch("alt_pack16_kernel");
+}
+
+int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float* maxpart, int B, int H, int W, int C, int L,
+                            int r, const float* coords, float* out, hipStream_t s)
+{
+    if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_fwd: radius %d > 7", r);
+    AltFwdArgs a = {};
+    a.f1p = (const uint4*)f1p;
+    for (int l = 0; l < L; ++l) { a.f2p[l] = (const uint4*)f2p[l]; a.hl[l] = H >> l; a.wl[l] = W >> l; }
+    a.coords = coords; a.out = out; a.maxpart = maxpart;
+    a.B = B; a.C = C; a.Cp = (C + 31) / 32 * 32; a.H = H; a.W = W; a.L = L; a.r = r;
+    a.sqrt_c = sqrtf((float)C);
+    if ((size_t)H * W * (a.Cp / 32) * 8 >= ((size_t)1 << 31))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_fwd: a packed map of %d x %d x %d exceeds 2^31 slots", H, W, C);
+    const int tiles = ((W + QW - 1) / QW) * ((H + QH - 1) / QH);
+    a.band = (tiles + 7) / 8;
+    const size_t sm = std::max((size_t)2 * UP * 8 * sizeof(uint4), (size_t)TQ * LDS_S * sizeof(float));
+    const dim3 grid(8u * a.band * L * B);
+    static thread_local bool allowed[64][2] = {};            // >64 KiB of dynamic LDS: opt in once per device and kernel
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    const int which = r <= 4 ? 0 : 1;
+    if (e == hipSuccess && !allowed[dev & 63][which]) {
+        e = which == 0 ? hipFuncSetAttribute((const void*)alt_fwd16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)
+                       : hipFuncSetAttribute((const void*)alt_fwd16_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e == hipSuccess) allowed[dev & 63][which] = true;
+    }
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_lookup_fwd: %s", hipGetErrorString(e));
+    if (which == 0) hipLaunchKernelGGL(alt_fwd16_kernel<4>, grid, dim3(256), sm, s, a);
+    else            hipLaunchKernelGGL(alt_fwd16_kernel<7>, grid, dim3(256), sm, s, a);
+    return check_launch("alt_fwd16_kernel");
+}
+
+}  // namespace raftcorr

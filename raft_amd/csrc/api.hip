@@ -265,17 +265,48 @@ int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* c
                                 B, N, H1, W1, H2, W2, C, radius, (hipStream_t)stream);
 }
 
-int raftcorr_alt_lookup_fwd(const float* fmap1, const float* const* fmap2_levels, int B, int H, int W,
-                            int C, int num_levels, int radius, const float* coords, float* out, void* stream)
+int64_t raftcorr_alt_packed_bytes(int B, int C, int H, int W)
+{
+    if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+    return (int64_t)alt_packed_bytes(B, C, H, W);
+}
+
+int raftcorr_alt_scales(const float* fmap1, const float* fmap2, int B, int C, int H, int W, float* scales, void* stream)
+{
+    int rc = check_dims("alt_scales", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !scales || C < 1) return fail(RAFTCORR_EINVAL, "alt_scales: bad argument");
+    return launch_maxabs(fmap1, fmap2, (size_t)B * C * H * W, scales, (hipStream_t)stream);
+}
+
+int raftcorr_alt_pack(const float* fmap, int B, int C, int H, int W, const float* scale, void* packed, int64_t packed_bytes,
+                      void* stream)
+{
+    int rc = check_dims("alt_pack", B, H, W);
+    if (rc) return rc;
+    if (!fmap || !scale || !packed || C < 1) return fail(RAFTCORR_EINVAL, "alt_pack: bad argument");
+    if (packed_bytes < (int64_t)alt_packed_bytes(B, C, H, W))
+        return fail(RAFTCORR_EINVAL, "alt_pack: packed buffer too small (%lld < %zu bytes)", (long long)packed_bytes,
+                    alt_packed_bytes(B, C, H, W));
+    return launch_alt_pack(fmap, B, C, H, W, scale, packed, (hipStream_t)stream);
+}
+
+int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_levels, const float* scales,
+                            int B, int H, int W, int C, int num_levels, int radius, const float* coords, float* out,
+                            void* stream)
 {
     int rc = check_dims("alt_lookup_fwd", B, H, W);
     if (rc) return rc;
-    if (!fmap1 || !coords || !out) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: null pointer");
+    if (!packed1 || !packed2_levels || !scales || !coords || !out) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: null pointer");
     if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: C=%d radius=%d", C, radius);
-    LevelSet lv;
-    rc = make_levels("alt_lookup_fwd", fmap2_levels, H, W, num_levels, lv, false);
-    if (rc) return rc;
-    return launch_alt_lookup_fwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, out, (hipStream_t)stream);
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: level %d of a %d x %d map is empty", l, H, W);
+        if (!packed2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: level %d pointer is null", l);
+    }
+    return launch_alt_lookup_fwd16(packed1, packed2_levels, scales, B, H, W, C, num_levels, radius, coords, out,
+                                   (hipStream_t)stream);
 }
 
 int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels, int B, int H, int W,

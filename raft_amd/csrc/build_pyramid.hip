@@ -423,6 +423,13 @@ void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ 
     if (threadIdx.x == 0) out[blockIdx.y * MAXPARTS + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// partial maxima of two equally sized maps (out: [2][MAXPARTS]); also the range pass of the on-the-fly path's pack
+int launch_maxabs(const float* f1, const float* f2, size_t n, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, n, out);
+    return check_launch("corr_maxabs_kernel");
+}
+
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 {
     unsigned u = __float_as_uint(x);

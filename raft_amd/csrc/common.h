@@ -40,8 +40,11 @@ int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, 
 int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,
                          float* g1, float* g2, float* gc,
                          int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
-int launch_alt_lookup_fwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
-                          int r, const float* coords, float* out, hipStream_t s);
+int launch_maxabs(const float* f1, const float* f2, size_t n, float* out, hipStream_t s);
+size_t alt_packed_bytes(int B, int C, int H, int W);
+int launch_alt_pack(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
+int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float* maxpart, int B, int H, int W, int C, int L,
+                            int r, const float* coords, float* out, hipStream_t s);
 int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
                           int r, const float* coords, const float* dout, float* df1,
                           const LevelSet& df2lv, hipStream_t s);
