@@ -8,7 +8,7 @@
 // cores; every query then picks its (2r+2)^2 taps out of S in LDS and blends them.  What is new:
 //
 //  * 8x8 = 64 queries per workgroup (two MFMA row blocks share every staged target), box walked in passes
-//    of 256 targets (8 MFMA column blocks); a pass computes only the column blocks that hold box targets.
+//    of 192 targets (6 MFMA column blocks); a pass computes only the column blocks that hold box targets.
 //  * The features are PACKED once per frame pair (raftcorr_alt_pack, the constructor of AlternateCorrBlock):
 //    each map is scaled by a power of two into the top of fp16's range and every value split into two fp16
 //    pieces x = hi + lo (22 significand bits).  The product is three v_mfma_f32_32x32x16_f16 terms
@@ -19,8 +19,10 @@
 //    (global_load_lds_dwordx4, 8 lanes per line, no VGPR round trip, no conversion), double buffered, one
 //    barrier per chunk; slots are XOR-swizzled by (row >> 1) & 7 on the way in (the DMA writes 1 KiB
 //    contiguously, the swizzle is applied to the SOURCE slot each lane fetches) so that the ds_read_b128
-//    fragment reads of 128-byte rows are bank-conflict-free.  A wave's query fragments are private to it
-//    and are read straight from global memory one chunk ahead.
+//    fragment reads of 128-byte rows are bank-conflict-free.  The query rows travel the same way: read
+//    straight from global memory as fragments (16 bytes per lane from 32 different lines per instruction,
+//    every line touched by four instructions of two waves) they cost more L1 -> L2 requests than all the
+//    targets together and made the loop request-bound (tools/alt_lab.py ablations: 15 of 50 us).
 #include "common.h"
 #include <limits.h>
 #include <algorithm>
@@ -30,7 +32,9 @@ namespace raftcorr {
 namespace {
 
 constexpr int QW = 8, QH = 8, TQ = QW * QH;       // query tile
-constexpr int UP = 256;                           // box targets per pass (8 MFMA column blocks)
+constexpr int UP = 192;                           // box targets per pass (6 MFMA column blocks)
+constexpr int NBW = UP / 64;                      // column blocks per wave
+constexpr int STG = (TQ + UP) * 8;                // uint4 slots per staging buffer: 64 query rows + UP target rows of 128 B
 constexpr int KC = 32;                            // channels per staged chunk = one 128-byte line per pixel
 constexpr int LDS_S = UP + 1;                     // S[q][u] row stride (odd: the per-query gathers are conflict-free)
 constexpr int MAXPARTS16 = 128;                   // partial maxima per map (corr_maxabs_kernel, build_pyramid.hip)
@@ -58,10 +62,8 @@ struct TileSh {
     int toff[UP];                                 // pixel index of the pass' box targets in the level, -1 beyond the box
 };
 
-__device__ __forceinline__ float wave_max128(const float* __restrict__ part)
+__device__ __forceinline__ float wave_max128(float m)       // m: max of this lane's two partial maxima
 {
-    const int lane = threadIdx.x & 63;
-    float m = fmaxf(part[lane], part[lane + 64]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     return m;
@@ -83,7 +85,7 @@ void alt_pack16_kernel(const float* __restrict__ f, uint4* __restrict__ packed, 
                        const float* __restrict__ maxpart)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x, c0 = blockIdx.y * 8, b = blockIdx.z;
-    const float scale = ldexpf(1.0f, range_exp16(wave_max128(maxpart)));
+    const float scale = ldexpf(1.0f, range_exp16(wave_max128(fmaxf(maxpart[threadIdx.x & 63], maxpart[(threadIdx.x & 63) + 64]))));
     if (pix >= HW) return;
     float x[8];
 #pragma unroll
@@ -175,28 +177,46 @@ __device__ __forceinline__ Tile16 tile_setup16(const AltFwdArgs& p, TileSh& sh)
 
 // ---------------------------------------------------------------------------------------------
 // forward.  grid: 8 XCD bands x (tiles per band x L x B), block 256 = 4 waves.
-// wave w: MFMA row block mb = w & 1 (32 of the 64 queries), column blocks (w >> 1) + 2 j, j = 0..3.
+// wave w: MFMA row block mb = w & 1 (32 of the 64 queries), column blocks (w >> 1) + 2 j, j < NBW.
 // RMAX: largest radius the instantiation's register arrays hold.
 template <int RMAX>
 __global__ __launch_bounds__(256, 2)
 void alt_fwd16_kernel(AltFwdArgs p)
 {
     constexpr int RDM = 2 * RMAX + 1, NCOL = (RDM + 3) / 4;  // window columns per thread (4 threads per query)
-    extern __shared__ __attribute__((aligned(16))) uint4 smem[];     // 2 x [UP rows][8 slots] staging; later S[TQ][LDS_S]
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];     // 2 x [TQ + UP rows][8 slots] staging; later S[TQ][LDS_S]
     __shared__ TileSh sh;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = p.r, rd = 2 * r + 1, rd2 = rd * rd, T = 2 * r + 2;
+#if defined(RC_LAB_STAMPS)
+    unsigned long long* stamps = (unsigned long long*)p.out + (size_t)blockIdx.x * 16;
+    int nst = 0;
+#define ALT_STAMP() do { if (threadIdx.x == 0 && nst < 16) stamps[nst] = __builtin_amdgcn_s_memrealtime(); ++nst; } while (0)
+#else
+#define ALT_STAMP()
+#endif
+    ALT_STAMP();
+    // partial maxima behind the unscale factor: fetched now, used after the last pass (a dependent fetch there
+    // would add a memory round trip to every workgroup's critical path)
+    const float mp1 = fmaxf(p.maxpart[threadIdx.x & 63], p.maxpart[(threadIdx.x & 63) + 64]);
+    const float mp2 = fmaxf(p.maxpart[MAXPARTS16 + (threadIdx.x & 63)], p.maxpart[MAXPARTS16 + (threadIdx.x & 63) + 64]);
     const Tile16 t = tile_setup16(p, sh);
     if (!t.live) return;
+    ALT_STAMP();
     const int nkc = p.Cp / KC;
     const size_t P = (size_t)p.H * p.W;
     const int mb = wave & 1, nb0 = wave >> 1;
 
-    // this lane's A fragments (query row mb*32 + l31): slot = piece * 4 + k-step * 2 + kh of every chunk's line
-    const int myq = sh.qpix[mb * 32 + l31];
-    const uint4* __restrict__ arow = p.f1p + ((size_t)t.b * P + max(myq, 0)) * nkc * 8 + kh;
+    const uint4* __restrict__ f1b = p.f1p + (size_t)t.b * P * nkc * 8;
     const uint4* __restrict__ f2b = p.f2p[t.l] + (size_t)t.b * t.HWl * nkc * 8;
+    // DMA source of this lane for the query rows: row groups wave and 4 + wave (8 rows each)
+    unsigned asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (i * 4 + wave) * 8 + (lane >> 3);
+        asrc[i] = (unsigned)max(sh.qpix[rr], 0) * (unsigned)(nkc * 8) + (unsigned)((lane & 7) ^ ((rr >> 1) & 7));
+    }
 
     // outputs of this thread: query qi = tid & 63, window columns a = g4 + 4 i (g4 = wave: uniform per wave)
     const int qi = tid & 63, g4 = wave;
@@ -206,8 +226,6 @@ void alt_fwd16_kernel(AltFwdArgs p)
 #pragma unroll
         for (int bb = 0; bb < RDM; ++bb) o[i][bb] = 0.f;
 
-    uint4* stg0 = smem;
-    uint4* stg1 = smem + UP * 8;
     float* S = (float*)smem;
 
     for (int ubase = 0; ubase < t.U; ubase += UP) {
@@ -216,74 +234,85 @@ void alt_fwd16_kernel(AltFwdArgs p)
             const int u = ubase + tid;
             int off = -1;
             if (u < t.U) { const int uy = u / t.bw, ux = u - uy * t.bw; off = (t.ymin + uy) * t.Wl + t.xmin + ux; }
-            sh.toff[tid] = off;
+            if (tid < UP) sh.toff[tid] = off;
         }
         __syncthreads();
         const int nlive = min(t.U - ubase, UP);
-        // DMA sources of this lane for the pass: 8 row groups of 8 targets per wave (rows (i*4 + wave)*8 + lane/8);
+        ALT_STAMP();
+        // DMA sources of this lane for the pass: UP/32 row groups of 8 targets per wave (rows (i*4 + wave)*8 + lane/8);
         // LDS slot lane&7 of row rr receives source slot (lane&7) ^ ((rr >> 1) & 7)
-        unsigned src[8];
+        unsigned src[UP / 32];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < UP / 32; ++i) {
             const int rr = (i * 4 + wave) * 8 + (lane >> 3);
             src[i] = (unsigned)max(sh.toff[rr], 0) * (unsigned)(nkc * 8) + (unsigned)((lane & 7) ^ ((rr >> 1) & 7));
         }
-        auto stage = [&](int kc, uint4* buf) {
+        auto stage = [&](int kc, uint4* buf) {               // buf: [TQ query rows | UP target rows] x 8 slots
+#if !defined(RC_LAB_NOSTAGE)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 2; ++i) glds16(f1b + asrc[i] + kc * 8, buf + (i * 4 + wave) * 64);
+#pragma unroll
+            for (int i = 0; i < UP / 32; ++i)
                 if ((i * 4 + wave) * 8 < nlive)              // wave-uniform: row groups beyond the box are not fetched
-                    glds16(f2b + src[i] + kc * 8, buf + (i * 4 + wave) * 64);
+                    glds16(f2b + src[i] + kc * 8, buf + TQ * 8 + (i * 4 + wave) * 64);
+#endif
         };
-        uint4 a_nxt[4], a_cur[4];
-        auto load_a = [&](int kc) {
+        v16f acc[NBW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a_nxt[i] = arow[kc * 8 + i * 2];       // slots kh, 2+kh (hi), 4+kh, 6+kh (lo)
-        };
-        v16f acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NBW; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        // live column blocks of this wave (blocks nb0 + 2 j), wave-uniform
+        const int nlb = nb0 * 32 < nlive ? min((nlive - nb0 * 32 + 63) / 64, NBW) : 0;
+        const int key = (l31 >> 1) & 7;                      // (row >> 1) & 7 for rows nb*32 + l31 and mb*32 + l31
 
-        // K-chunk body with restrict-qualified buffers: after inlining, the DMA destination (`nxt`) and the
-        // fragment source (`cur`) carry distinct alias scopes -- with one array and a run-time buffer index hipcc
-        // waits vmcnt(0) before the first fragment read and the next chunk's DMA no longer flies under the MFMAs
-        // (build_pyramid.hip has the same construction)
+        // One K chunk.  The buffers are restrict-qualified parameters: after inlining, the DMA destination and the
+        // fragment source carry distinct alias scopes, so hipcc does not put `s_waitcnt vmcnt(0)` in front of the
+        // fragment reads while the next chunk's DMA is in flight (build_pyramid.hip has the same construction).
         auto kchunk = [&](int kc, const uint4* __restrict__ cur, uint4* __restrict__ nxt) {
-            __syncthreads();                                 // chunk kc has landed (vmcnt(0) precedes the barrier) and
-                                                             // nobody reads the buffer that is restaged next
+            // A bare s_barrier: __syncthreads() carries a fence.  After it everybody's part of chunk kc has landed
+            // (vmcnt counts a DMA once its data is in LDS) and nobody still reads the buffer that is restaged next.
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kc + 1 < nkc) stage(kc + 1, nxt);
+#if !defined(RC_LAB_NOMFMA)
+            const uint4* arow = cur + (mb * 32 + l31) * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
-            if (kc + 1 < nkc) { stage(kc + 1, nxt); load_a(kc + 1); }
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, arow[(s * 2 + kh) ^ key]);
+                const f16x8 al = __builtin_bit_cast(f16x8, arow[(4 + s * 2 + kh) ^ key]);
+                f16x8 bh[NBW], bl[NBW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = nb0 + 2 * j;
-                if (nb * 32 < nlive) {                       // wave-uniform
-                    const int rr = nb * 32 + l31, key = (rr >> 1) & 7;
-                    const uint4* brow = cur + rr * 8;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const uint4 bh = brow[(s * 2 + kh) ^ key], bl = brow[(4 + s * 2 + kh) ^ key];
-                        const f16x8 ah = __builtin_bit_cast(f16x8, a_cur[s]), al = __builtin_bit_cast(f16x8, a_cur[2 + s]);
-                        // small terms first: lo*hi, hi*lo, hi*hi
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, bh), acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bl), acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bh), acc[j], 0, 0, 0);
+                for (int j = 0; j < NBW; ++j)
+                    if (j < nlb) {
+                        const uint4* brow = cur + TQ * 8 + ((nb0 + 2 * j) * 32 + l31) * 8;
+                        bh[j] = __builtin_bit_cast(f16x8, brow[(s * 2 + kh) ^ key]);
+                        bl[j] = __builtin_bit_cast(f16x8, brow[(4 + s * 2 + kh) ^ key]);
                     }
-                }
+                // small terms first (lo*hi, hi*lo, hi*hi); the live column blocks take turns inside each term, so
+                // that no MFMA waits for the one before it
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+                    if (j < nlb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+                    if (j < nlb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+                    if (j < nlb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
             }
+#endif
         };
-        stage(0, stg0);
-        load_a(0);
+        stage(0, smem);
         for (int kc = 0; kc < nkc; kc += 2) {
-            kchunk(kc, stg0, stg1);
-            if (kc + 1 < nkc) kchunk(kc + 1, stg1, stg0);
+            kchunk(kc, smem, smem + STG);
+            if (kc + 1 < nkc) kchunk(kc + 1, smem + STG, smem);
         }
         __syncthreads();                                     // staging buffers are free: S takes their place
+        ALT_STAMP();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NBW; ++j) {
             const int nb = nb0 + 2 * j;
-            if (nb * 32 < nlive) {
+            if (j < nlb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
@@ -292,6 +321,7 @@ void alt_fwd16_kernel(AltFwdArgs p)
             }
         }
         __syncthreads();
+        ALT_STAMP();
         // gather: window column a needs tap columns a, a+1 for the T tap rows; u = (wy+ty-ymin)*bw + (wx+tx-xmin) - ubase
         const int wx = sh.wx0[qi] - t.xmin, wy = sh.wy0[qi] - t.ymin;
         const float fx = sh.fx[qi], fy = sh.fy[qi];
@@ -320,8 +350,13 @@ void alt_fwd16_kernel(AltFwdArgs p)
             }
         }
     }
+    ALT_STAMP();
+#if defined(RC_LAB_STAMPS)
+    if (threadIdx.x == 0) { stamps[14] = (unsigned long long)t.l; stamps[15] = (unsigned long long)t.U; }
+    return;
+#endif
     const int myqi = sh.qpix[qi];
-    const float unscale = ldexpf(1.0f, -(range_exp16(wave_max128(p.maxpart)) + range_exp16(wave_max128(p.maxpart + MAXPARTS16))));
+    const float unscale = ldexpf(1.0f, -(range_exp16(wave_max128(mp1)) + range_exp16(wave_max128(mp2))));
     if (myqi >= 0) {
         float* __restrict__ out = p.out + (((size_t)t.b * p.L + t.l) * rd2) * P + myqi;
 #pragma unroll
@@ -366,7 +401,7 @@ int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float
         return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_fwd: a packed map of %d x %d x %d exceeds 2^31 slots", H, W, C);
     const int tiles = ((W + QW - 1) / QW) * ((H + QH - 1) / QH);
     a.band = (tiles + 7) / 8;
-    const size_t sm = std::max((size_t)2 * UP * 8 * sizeof(uint4), (size_t)TQ * LDS_S * sizeof(float));
+    const size_t sm = std::max((size_t)2 * STG * sizeof(uint4), (size_t)TQ * LDS_S * sizeof(float));
     const dim3 grid(8u * a.band * L * B);
     static thread_local bool allowed[64][2] = {};            // >64 KiB of dynamic LDS: opt in once per device and kernel
     int dev = 0;
