@@ -1,0 +1,90 @@
+// Shared by the on-the-fly kernels (alt_fwd16.hip, alt_bwd.hip): the 8x8 query tile, its window origins and the
+// bounding box of its windows at one level.
+#pragma once
+#include "common.h"
+#include <limits.h>
+
+namespace raftcorr {
+namespace {
+
+constexpr int QW = 8, QH = 8, TQ = QW * QH;       // query tile
+
+struct TileQ {
+    int wx0[TQ], wy0[TQ];                         // window origin (x0 - r, y0 - r) per query
+    float fx[TQ], fy[TQ];
+    int qpix[TQ];                                 // query pixel index, -1 outside the map
+    int box[4];
+};
+
+// Args needs: coords (B,2,H,W), hl[], wl[], H, W, L, r, band (tiles per XCD band).  Workgroup id -> (XCD band, tile,
+// level, batch): each XCD (id mod 8) owns a band of tiles, whose part of the target maps stays in that XCD's L2.
+struct Tile16 {
+    int b, l, ty0, tx0, Hl, Wl, HWl;
+    bool live;
+    int xmin, ymin, bw, bh, U;
+};
+
+// queries' window origins + the bounding box of their in-level parts (wave 0: one lane per query)
+// window origins of the tile's queries at level t.l + the bounding box of their in-level parts (wave 0: one lane
+// per query).  t.b, t.l, t.ty0, t.tx0 must be set; contains a barrier (every thread of the workgroup calls it).
+template <class Args>
+__device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile16& t)
+{
+    t.Hl = p.hl[t.l]; t.Wl = p.wl[t.l]; t.HWl = t.Hl * t.Wl;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int qi = tid, gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
+        const bool valid = gy < p.H && gx < p.W;
+        const int T = 2 * p.r + 2;
+        int wx0 = -(1 << 24), wy0 = -(1 << 24);
+        float fx = 0.f, fy = 0.f;
+        if (valid) {
+            const size_t P = (size_t)p.H * p.W, q = (size_t)gy * p.W + gx;
+            const float* c = p.coords + (size_t)t.b * 2 * P + q;
+            const float s = 1.0f / (float)(1 << t.l);        // exact power of two == coords / 2**l (corr.py:86)
+            int x0, y0;
+            split_coord(c[0] * s, x0, fx);
+            split_coord(c[P] * s, y0, fy);
+            wx0 = x0 - p.r; wy0 = y0 - p.r;
+        }
+        const int qx0 = max(wx0, 0), qx1 = min(wx0 + T - 1, t.Wl - 1);
+        const int qy0 = max(wy0, 0), qy1 = min(wy0 + T - 1, t.Hl - 1);
+        const bool has = valid && qx0 <= qx1 && qy0 <= qy1;
+        int mnx = has ? qx0 : INT_MAX, mxx = has ? qx1 : INT_MIN;
+        int mny = has ? qy0 : INT_MAX, mxy = has ? qy1 : INT_MIN;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, m)); mxx = max(mxx, __shfl_xor(mxx, m));
+            mny = min(mny, __shfl_xor(mny, m)); mxy = max(mxy, __shfl_xor(mxy, m));
+        }
+        sh.wx0[qi] = wx0; sh.wy0[qi] = wy0; sh.fx[qi] = fx; sh.fy[qi] = fy;
+        sh.qpix[qi] = valid ? gy * p.W + gx : -1;
+        if (tid == 0) { sh.box[0] = mnx; sh.box[1] = mxx; sh.box[2] = mny; sh.box[3] = mxy; }
+    }
+    __syncthreads();
+    const int mnx = sh.box[0], mxx = sh.box[1], mny = sh.box[2], mxy = sh.box[3];
+    if (mnx > mxx || mny > mxy) { t.xmin = 0; t.ymin = 0; t.bw = 1; t.bh = 0; t.U = 0; }
+    else { t.xmin = mnx; t.ymin = mny; t.bw = mxx - mnx + 1; t.bh = mxy - mny + 1; t.U = t.bw * t.bh; }
+}
+
+template <class Args>
+__device__ __forceinline__ Tile16 tile_setup16(const Args& p, TileQ& sh)
+{
+    Tile16 t;
+    const int tiles_x = (p.W + QW - 1) / QW, tiles = tiles_x * ((p.H + QH - 1) / QH);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int j = idx % p.band, bl = idx / p.band;
+    const int tile = xcd * p.band + j;
+    t.l = bl % p.L;
+    t.b = bl / p.L;
+    t.live = tile < tiles;
+    if (!t.live) return t;                                   // whole workgroup
+    t.ty0 = (tile / tiles_x) * QH;
+    t.tx0 = (tile % tiles_x) * QW;
+    tile_level_setup(p, sh, t);
+    return t;
+}
+
+
+}  // namespace
+}  // namespace raftcorr

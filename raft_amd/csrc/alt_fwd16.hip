@@ -24,14 +24,13 @@
 //    every line touched by four instructions of two waves) they cost more L1 -> L2 requests than all the
 //    targets together and made the loop request-bound (tools/alt_lab.py ablations: 15 of 50 us).
 #include "common.h"
-#include <limits.h>
+#include "alt_common.h"
 #include <algorithm>
 
 namespace raftcorr {
 
 namespace {
 
-constexpr int QW = 8, QH = 8, TQ = QW * QH;       // query tile
 constexpr int UP = 192;                           // box targets per pass (6 MFMA column blocks)
 constexpr int NBW = UP / 64;                      // column blocks per wave
 constexpr int STG = (TQ + UP) * 8;                // uint4 slots per staging buffer: 64 query rows + UP target rows of 128 B
@@ -54,11 +53,7 @@ struct AltFwdArgs {
     float sqrt_c;
 };
 
-struct TileSh {
-    int wx0[TQ], wy0[TQ];                         // window origin (x0 - r, y0 - r) per query
-    float fx[TQ], fy[TQ];
-    int qpix[TQ];                                 // query pixel index, -1 outside the map
-    int box[4];
+struct TileSh : TileQ {
     int toff[UP];                                 // pixel index of the pass' box targets in the level, -1 beyond the box
 };
 
@@ -115,64 +110,6 @@ __device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_chunk)
     // 64 lanes x 16 B: per-lane global source, LDS destination = chunk base + lane * 16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
-}
-
-struct Tile16 {
-    int b, l, ty0, tx0, Hl, Wl, HWl;
-    bool live;
-    int xmin, ymin, bw, bh, U;
-};
-
-// queries' window origins + the bounding box of their in-level parts (wave 0: one lane per query)
-__device__ __forceinline__ Tile16 tile_setup16(const AltFwdArgs& p, TileSh& sh)
-{
-    Tile16 t;
-    const int tiles_x = (p.W + QW - 1) / QW, tiles = tiles_x * ((p.H + QH - 1) / QH);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int j = idx % p.band, bl = idx / p.band;
-    const int tile = xcd * p.band + j;
-    t.l = bl % p.L;
-    t.b = bl / p.L;
-    t.live = tile < tiles;
-    if (!t.live) return t;                                   // whole workgroup
-    t.ty0 = (tile / tiles_x) * QH;
-    t.tx0 = (tile % tiles_x) * QW;
-    t.Hl = p.hl[t.l]; t.Wl = p.wl[t.l]; t.HWl = t.Hl * t.Wl;
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int qi = tid, gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
-        const bool valid = gy < p.H && gx < p.W;
-        const int T = 2 * p.r + 2;
-        int wx0 = -(1 << 24), wy0 = -(1 << 24);
-        float fx = 0.f, fy = 0.f;
-        if (valid) {
-            const size_t P = (size_t)p.H * p.W, q = (size_t)gy * p.W + gx;
-            const float* c = p.coords + (size_t)t.b * 2 * P + q;
-            const float s = 1.0f / (float)(1 << t.l);        // exact power of two == coords / 2**l (corr.py:86)
-            int x0, y0;
-            split_coord(c[0] * s, x0, fx);
-            split_coord(c[P] * s, y0, fy);
-            wx0 = x0 - p.r; wy0 = y0 - p.r;
-        }
-        const int qx0 = max(wx0, 0), qx1 = min(wx0 + T - 1, t.Wl - 1);
-        const int qy0 = max(wy0, 0), qy1 = min(wy0 + T - 1, t.Hl - 1);
-        const bool has = valid && qx0 <= qx1 && qy0 <= qy1;
-        int mnx = has ? qx0 : INT_MAX, mxx = has ? qx1 : INT_MIN;
-        int mny = has ? qy0 : INT_MAX, mxy = has ? qy1 : INT_MIN;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, m)); mxx = max(mxx, __shfl_xor(mxx, m));
-            mny = min(mny, __shfl_xor(mny, m)); mxy = max(mxy, __shfl_xor(mxy, m));
-        }
-        sh.wx0[qi] = wx0; sh.wy0[qi] = wy0; sh.fx[qi] = fx; sh.fy[qi] = fy;
-        sh.qpix[qi] = valid ? gy * p.W + gx : -1;
-        if (tid == 0) { sh.box[0] = mnx; sh.box[1] = mxx; sh.box[2] = mny; sh.box[3] = mxy; }
-    }
-    __syncthreads();
-    const int mnx = sh.box[0], mxx = sh.box[1], mny = sh.box[2], mxy = sh.box[3];
-    if (mnx > mxx || mny > mxy) { t.xmin = 0; t.ymin = 0; t.bw = 1; t.bh = 0; t.U = 0; }
-    else { t.xmin = mnx; t.ymin = mny; t.bw = mxx - mnx + 1; t.bh = mxy - mny + 1; t.U = t.bw * t.bh; }
-    return t;
 }
 
 // ---------------------------------------------------------------------------------------------
