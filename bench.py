@@ -397,26 +397,29 @@ def extras_kitti(torch, wl, dev):
     out = {}
     with torch.no_grad():
         blk = AlternateCorrBlock(wl.f1.detach(), wl.f2.detach(), num_levels=LEVELS, radius=RADIUS)
-        f1n = blk.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
-        f2n = [blk.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(LEVELS)]
+        f1g = wl.f1.detach().clone().requires_grad_(True)               # a block that packed the backward's copies
+        with torch.enable_grad():
+            gblk = AlternateCorrBlock(f1g, wl.f2.detach(), num_levels=LEVELS, radius=RADIUS)
         gout = wl.gouts[0]
-        d1 = torch.empty_like(f1n)
-        d2 = [torch.zeros_like(t) for t in f2n]
-        lv, dlv = _lib.ptr_array(f2n), _lib.ptr_array(d2)
+        d1 = torch.empty(B, H, W, D, device=dev)
+        d2 = [torch.empty(B, H >> l, W >> l, D, device=dev) for l in range(LEVELS)]
+        dlv = _lib.ptr_array(d2)
+        wb = lib.raftcorr_alt_lookup_bwd_workspace_bytes(B, H, W, D, LEVELS, RADIUS)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         o = torch.empty(B, LEVELS * 81, H, W, device=dev)
         for tag, c in (("identity", wl.coords[0]), ("sigma3", wl.coords[1]), ("sigma6", wl.coords[4])):
             tf = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(),
                                                                       B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
                                                                       stream))
-            tb = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(f1n.data_ptr(), lv, B, H, W, D, LEVELS, RADIUS,
-                                                                      c.data_ptr(), gout.data_ptr(), d1.data_ptr(), dlv,
-                                                                      stream))
-            out["alt_fwd_" + tag] = frac_entry("alt_fwd_kernel", tf, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
+            tb = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(gblk._t1.data_ptr(), gblk._t2ptrs, gblk._scales.data_ptr(),
+                                                                      B, H, W, D, LEVELS, RADIUS, c.data_ptr(), gout.data_ptr(),
+                                                                      d1.data_ptr(), dlv, work.data_ptr(), wb, stream))
+            out["alt_fwd_" + tag] = frac_entry("alt_fwd16_kernel", tf, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
                                                "TFLOP/s", hbm_GBs=w["alt_bytes"] / tf / 1e3,
                                                hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS,
                                                compulsory_bytes=w["alt_bytes"])
-            out["alt_bwd_" + tag] = frac_entry("alt_bwd_kernel(s)", tb, "mfma", w["alt_bwd_flops"],
+            out["alt_bwd_" + tag] = frac_entry("corr_maxabs + alt_boxes + alt_bwd + alt_bwd_reduce kernels", tb, "mfma", w["alt_bwd_flops"],
                                                MFMA_F32_PEAK_TFLOPS, "TFLOP/s", hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
                                                hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS,
                                                compulsory_bytes=w["alt_bwd_bytes"])

@@ -175,7 +175,10 @@ int raftcorr_alt_forward(const float* fmap1, const float* fmap2, const float* co
 /* Drop-in for alt_cuda_corr.backward (alt_cuda_corr/correlation.cpp:36-48 ->
  * correlation_kernel.cu:288-324).  fmap1_grad (B,H1,W1,C), fmap2_grad (B,H2,W2,C) and
  * coords_grad (B,N,H1,W1,2) are fully overwritten; coords_grad is all zeros, as in the
- * reference (allocated at :307 and never written). coords_grad may be NULL. */
+ * reference (allocated at :307 and never written). coords_grad may be NULL.  Like the reference kernel
+ * (atomicAdd at :229-238) this one-level drop-in zero-fills both gradients and adds into them with float
+ * atomics, so the summation order -- not the value beyond rounding -- varies from run to run; the
+ * all-level call below (raftcorr_alt_lookup_bwd) is the atomic-free, reproducible path. */
 int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* coords,
                           const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
                           float* coords_grad,
@@ -206,15 +209,31 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, float* out, void* stream);
 
-/* Backward of raftcorr_alt_lookup_fwd w.r.t. the features (the reference exports corr_backward,
- * correlation.cpp:36-48, but never wires it into autograd).  fmap1 (B,H,W,C) and fmap2_levels[l]
- * (B,H_l,W_l,C): float32 NHWC as the reference kernel takes them (correlation_kernel.cu:22-24).
- * dfmap1 (B,H,W,C) is zeroed and accumulated here; dfmap2_levels[l] (B,H_l,W_l,C) must be zeroed by the
- * caller and is accumulated with float atomics (targets collide across queries). */
-int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels,
+/* Backward of raftcorr_alt_lookup_fwd w.r.t. the features, all levels (the reference exports corr_backward,
+ * correlation.cpp:36-48 -> correlation_kernel.cu:123-256, but never wires it into autograd; per level this is that
+ * kernel's arithmetic: g = bilinear-weighted sum of <= 4 d(out) cells per tap, d(fmap1) += g * fmap2,
+ * d(fmap2) += g * fmap1, then the 1/sqrt(C) of corr.py:92).  No atomics and no zero-filled outputs: every element of
+ * dfmap1 and of each dfmap2 level has one writer, sums run in a fixed order, results are bit-reproducible.
+ *   raftcorr_alt_pack_tiles   one map (B,C,H,W) float32 NCHW -> TILE-MAJOR packed copy for the backward pass: per 8x8
+ *                         pixel tile and channel 256 bytes of two fp16 pieces per value (same power-of-two scaling and
+ *                         `scale` argument as raftcorr_alt_pack); packed: raftcorr_alt_tiles_bytes(B, C, H, W) bytes
+ *   raftcorr_alt_lookup_bwd   tiles1: fmap1; tiles2_levels: HOST array of DEVICE pointers, level l = packed avg-pooled
+ *                         fmap2 ((B,C,H>>l,W>>l)); scales: as for the forward call; coords (B,2,H,W); dout
+ *                         (B, L*rd*rd, H, W); dfmap1 (B,H,W,C) and dfmap2_levels[l] (B,H_l,W_l,C) float32 NHWC (the
+ *                         layout of the reference kernel's gradients, correlation_kernel.cu:304-306), fully
+ *                         overwritten; workspace: raftcorr_alt_lookup_bwd_workspace_bytes(...) bytes of caller-allocated
+ *                         device memory, 256-byte aligned, contents don't-care before and after.
+ *                         Arithmetic: fp16x2 split operands (features as packed; g scaled by a power of two taken from
+ *                         max|dout|), three fp16 MFMA terms, fp32 accumulation: fp32-grade (gradient parity <= 2e-5). */
+int64_t raftcorr_alt_tiles_bytes(int B, int C, int H, int W);
+int raftcorr_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* scale, void* packed,
+                            int64_t packed_bytes, void* stream);
+int64_t raftcorr_alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius);
+int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels, const float* scales,
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, const float* dout,
-                            float* dfmap1, float* const* dfmap2_levels, void* stream);
+                            float* dfmap1, float* const* dfmap2_levels,
+                            void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

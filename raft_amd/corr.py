@@ -432,32 +432,38 @@ def _alt_forward(blk, coords):
 
 
 class _AltLookup(torch.autograd.Function):
-    """All levels of the on-the-fly correlation in one launch (forward); backward w.r.t. the features
-    from their float32 NHWC copies (the layout of the reference kernel, correlation_kernel.cu:22-24)."""
+    """All levels of the on-the-fly correlation in one launch (forward) and its gradient w.r.t. the features
+    (raftcorr_alt_lookup_bwd: tile-major packed features, no atomics, bit-reproducible).  fmap1 and the fmap2
+    levels are graph inputs only: the kernels read the block's packed copies."""
 
     @staticmethod
     def forward(ctx, coords, blk, fmap1, *fmap2_levels):
-        ctx.radius = blk.radius
-        ctx.save_for_backward(coords, fmap1, *fmap2_levels)
+        ctx.blk = blk
+        ctx.shapes = [tuple(t.shape) for t in fmap2_levels]
+        ctx.save_for_backward(coords)
         return _alt_forward(blk, coords)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         lib = _lib.load()
-        coords, fmap1, *levels = ctx.saved_tensors
-        B, H, W, C = fmap1.shape
-        L = len(levels)
+        (coords,) = ctx.saved_tensors
+        blk = ctx.blk
+        B, C, H, W = blk._shape
+        L = blk.num_levels
         dout = _f32c(dout)
-        d1 = torch.empty_like(fmap1)
-        d2 = [torch.zeros_like(t) for t in levels]
-        with _guard(fmap1):
-            _lib.check(lib.raftcorr_alt_lookup_bwd(fmap1.data_ptr(), _lib.ptr_array(levels), B, H, W, C, L,
-                                                   ctx.radius, coords.data_ptr(), dout.data_ptr(),
-                                                   d1.data_ptr(), _lib.ptr_array(d2), _stream(fmap1)),
-                       "alt_lookup_bwd")
+        dev = coords.device
+        d1 = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)             # NHWC, fully overwritten
+        d2 = [torch.empty(b, h, w, c, dtype=torch.float32, device=dev) for (b, c, h, w) in ctx.shapes]
+        wbytes = lib.raftcorr_alt_lookup_bwd_workspace_bytes(B, H, W, C, L, blk.radius)
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        with _guard(coords):
+            _lib.check(lib.raftcorr_alt_lookup_bwd(blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
+                                                   blk.radius, coords.data_ptr(), dout.data_ptr(),
+                                                   d1.data_ptr(), _lib.ptr_array(d2), work.data_ptr(), wbytes,
+                                                   _stream(coords)), "alt_lookup_bwd")
         # coords gradient: the reference kernel never writes it (correlation_kernel.cu:307)
-        return (None, None, d1, *d2)
+        return (None, None, d1.permute(0, 3, 1, 2), *[t.permute(0, 3, 1, 2) for t in d2])
 
 
 class AlternateCorrBlock:
@@ -513,10 +519,20 @@ class AlternateCorrBlock:
             self._p2 = [pack(t, self._scales.data_ptr() + 128 * 4) for t in f2]
         self._p2ptrs = _lib.ptr_array(self._p2)
         self._grad = torch.is_grad_enabled() and (self.pyramid[0][0].requires_grad or self.pyramid[0][1].requires_grad)
-        self._f1 = self._f2 = None                              # float32 NHWC copies, for the backward pass only
+        self._t1 = self._t2 = self._t2ptrs = None               # tile-major packed copies, for the backward pass only
         if self._grad:
-            self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
-            self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+            with _guard(f1):
+                def pack_tiles(t, scale_ptr):
+                    b, c, h, w = t.shape
+                    nbytes = lib.raftcorr_alt_tiles_bytes(b, c, h, w)
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    _lib.check(lib.raftcorr_alt_pack_tiles(t.data_ptr(), b, c, h, w, scale_ptr, buf.data_ptr(), nbytes, st),
+                               "alt_pack_tiles")
+                    return buf
+
+                self._t1 = pack_tiles(f1, self._scales.data_ptr())
+                self._t2 = [pack_tiles(t, self._scales.data_ptr() + 128 * 4) for t in f2]
+            self._t2ptrs = _lib.ptr_array(self._t2)
 
     def __call__(self, coords):
         _require_cuda(coords=coords)
@@ -527,5 +543,5 @@ class AlternateCorrBlock:
             raise RuntimeError(f"AlternateCorrBlock: coords must be ({B}, 2, {H}, {W}); got {tuple(coords.shape)}")
         coords = _f32c(coords).detach()
         if self._grad and torch.is_grad_enabled():
-            return _AltLookup.apply(coords, self, self._f1, *self._f2)
+            return _AltLookup.apply(coords, self, self.pyramid[0][0], *[self.pyramid[i][1] for i in range(self.num_levels)])
         return _alt_forward(self, coords)

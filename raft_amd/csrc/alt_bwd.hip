@@ -1,0 +1,555 @@
+// On-the-fly ("alternate") correlation, backward w.r.t. the features, all levels: no atomics, no memsets,
+// bit-reproducible.  Gradient of AlternateCorrBlock.__call__ (core/corr.py:75-92); per level the arithmetic of
+// alt_cuda_corr's corr_backward_kernel (correlation_kernel.cu:123-256: g = bilinear-weighted sum of <= 4 corr_grad
+// cells per tap, fmap1_grad += g * fmap2, fmap2_grad += g * fmap1), which the reference writes with one atomicAdd per
+// (query, tap, channel) (:229-238) and the round-1 kernel with one per (tile, box target, channel).
+//
+// Both gradients are sums over (query, tap) pairs of g[q][u] times the OTHER map's feature vector:
+//     d(fmap1)[q][c]   = sum_l sum_u g_l[q][u] fmap2_l[u][c]          d(fmap2_l)[u][c] = sum_q g_l[q][u] fmap1[q][c]
+// and each of them has a natural OWNER: a workgroup that owns an 8x8 tile of queries walks the 8x8 target tiles its
+// windows touch, one that owns an 8x8 tile of level-l targets walks the query tiles whose windows touch it.  Either
+// way one STEP is the same dense 64 x 64 block: build G[q][u] from the 2x2-filtered d(out) window of every query
+// (zero where u is not a tap of q), multiply it with the partner tile's features on the 16-bit matrix cores and keep
+// the owner's 64 x 128 slice of the gradient in registers until it is stored -- once, by its only writer.
+//
+//  * Operands: the features are packed once per frame pair TILE-MAJOR (raftcorr_alt_pack_tiles): per 8x8 pixel tile
+//    and channel 256 bytes = [hi | lo] fp16 pieces of the 64 pixels (the fp16x2 scheme of alt_fwd16.hip: maps scaled
+//    by a power of two into the top of fp16's range, x = hi + lo, 22 significand bits).  The contraction index of both
+//    products is a PIXEL index, so an MFMA operand fragment (8 consecutive k) is one row of 8 pixels of one channel =
+//    one 16-byte slot, and a partner tile's 128-channel slice is 32 KiB of contiguous memory that goes to LDS by
+//    direct-to-LDS DMA.  G is scaled by a power of two taken from max|d(out)| (one small range pass) and split the
+//    same way; the product is hi*hi + hi*lo + lo*hi in fp32 accumulators, unscaled exactly at the end.
+//  * LDS images have 256-byte rows (row = query / target / channel, 16 slots); slot j of row r lives at j ^ (r & 15),
+//    which makes the ds_read_b128 fragment reads conflict-free (the DMA applies the XOR to its source address).
+//  * d(fmap1): workgroup = (query tile, 128-channel group), all levels -> stored directly.  d(fmap2_l): workgroup =
+//    (target tile, channel group, split s of the list of overlapping query tiles); level 0 stores directly, the
+//    coarser levels (few target tiles, each touched by hundreds of query tiles) write per-split partial tiles that a
+//    small second kernel adds in a fixed order.  The list comes from a table of per-(level, query tile) window
+//    bounding boxes (alt_boxes_kernel) and is walked in increasing tile order: the summation order never changes.
+#include "common.h"
+#include "alt_common.h"
+#include <algorithm>
+
+namespace raftcorr {
+
+namespace {
+
+constexpr int NCB = 4;                            // MFMA column blocks (32 channels each) per workgroup
+constexpr int CG = 32 * NCB;                      // channels per workgroup
+constexpr int IMG_A = TQ * 16;                    // uint4 slots of the G image  [64 rows][16 slots]
+constexpr int IMG_B = CG * 16;                    // uint4 slots of the partner image [CG channel rows][16 slots]
+constexpr int MAXSPLIT = 32;
+
+struct AltBwdArgs {
+    const uint4* f1t;                             // tile-major fmap1: [B][qtiles][Cp][16 slots]
+    const uint4* f2t[RAFTCORR_MAX_LEVELS];        // tile-major pooled fmap2, level l: [B][ttiles_l][Cp][16]
+    int hl[RAFTCORR_MAX_LEVELS], wl[RAFTCORR_MAX_LEVELS];
+    const float* coords;                          // (B, 2, H, W)
+    const float* dout;                            // (B, L*rd*rd, H, W)
+    const float* maxpart;                         // [2][128] partial maxima of |fmap1|, |fmap2| (pack scales)
+    const float* dmax;                            // [128] partial maxima of |dout|
+    float* df1;                                   // (B, H, W, C)
+    float* df2[RAFTCORR_MAX_LEVELS];              // (B, H_l, W_l, C)
+    int4* boxes;                                  // [B][L][qtiles]: (xmin, xmax, ymin, ymax) of the tile's windows at level l
+    float* partial;                               // d(fmap2) partial tiles of the split levels
+    long long poff[RAFTCORR_MAX_LEVELS];          // level l's offset in `partial` (floats)
+    int nsplit[RAFTCORR_MAX_LEVELS];
+    int seg[RAFTCORR_MAX_LEVELS + 1];             // workgroups [0, seg[0]): d(fmap1); [seg[l], seg[l+1]): d(fmap2_l)
+    int B, C, Cp, H, W, L, r;
+    int qtx, qtiles, ngroups;
+    float sqrt_c;
+};
+
+struct BwdSh : TileQ {
+    int list[256];
+    int wc[4];
+};
+
+__device__ __forceinline__ int ttx_of(const AltBwdArgs& p, int l) { return (p.wl[l] + 7) >> 3; }
+__device__ __forceinline__ int ttiles_of(const AltBwdArgs& p, int l) { return ttx_of(p, l) * ((p.hl[l] + 7) >> 3); }
+
+// ---------------------------------------------------------------------------------------------
+// tile-major pack: (B, C, Hm, Wm) fp32 NCHW -> [B][tile][Cp][hi 8 rows | lo 8 rows][8 px] fp16, scaled, zero padded.
+// grid (tiles, Cp / 32, B), block 256: thread = (row = tid & 7, channel = tid >> 3)
+__global__ __launch_bounds__(256)
+void alt_pack_tiles_kernel(const float* __restrict__ f, uint4* __restrict__ packed, int C, int Cp, int Hm, int Wm,
+                           const float* __restrict__ maxpart)
+{
+    const float scale = ldexpf(1.0f, range_exp16(wave_max128(fmaxf(maxpart[threadIdx.x & 63], maxpart[(threadIdx.x & 63) + 64]))));
+    const int tx_n = (Wm + 7) >> 3;
+    const int tile = blockIdx.x, row = threadIdx.x & 7, c = blockIdx.y * 32 + (threadIdx.x >> 3), b = blockIdx.z;
+    const int y = (tile / tx_n) * 8 + row, x0 = (tile % tx_n) * 8;
+    const bool live = c < C && y < Hm;
+    const float* src = f + ((size_t)b * C + min(c, C - 1)) * Hm * Wm + (size_t)min(y, Hm - 1) * Wm;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[min(x0 + j, Wm - 1)];                 // all 8 loads in flight
+    unsigned short h[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (live && x0 + j < Wm) ? x[j] * scale : 0.f;
+        const _Float16 hi = (_Float16)v;                     // RNE
+        const _Float16 lo = (_Float16)(v - (float)hi);       // exact remainder, rounded once
+        h[0][j] = __builtin_bit_cast(unsigned short, hi);
+        h[1][j] = __builtin_bit_cast(unsigned short, lo);
+    }
+    uint4* dst = packed + (((size_t)b * gridDim.x + tile) * Cp + c) * 16 + row;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+        uint4 w;
+        w.x = h[pc][0] | ((unsigned)h[pc][1] << 16); w.y = h[pc][2] | ((unsigned)h[pc][3] << 16);
+        w.z = h[pc][4] | ((unsigned)h[pc][5] << 16); w.w = h[pc][6] | ((unsigned)h[pc][7] << 16);
+        dst[pc * 8] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// window bounding boxes: grid B * L * qtiles, block 64
+__global__ __launch_bounds__(64)
+void alt_boxes_kernel(AltBwdArgs p)
+{
+    __shared__ TileQ sh;
+    const int tile = blockIdx.x % p.qtiles, bl = blockIdx.x / p.qtiles;
+    Tile16 t;
+    t.l = bl % p.L; t.b = bl / p.L;
+    t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
+    tile_level_setup(p, sh, t);
+    if (threadIdx.x == 0) p.boxes[blockIdx.x] = make_int4(sh.box[0], sh.box[1], sh.box[2], sh.box[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pieces of one step
+
+// 8 scaled gradients -> two fp16 pieces -> slots `slot` (hi) and 8 + slot (lo) of row `row` of the G image
+__device__ __forceinline__ void store_g(uint4* img, int row, int slot, const float (&g)[8])
+{
+    unsigned short h[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hi = (_Float16)g[j];
+        const _Float16 lo = (_Float16)(g[j] - (float)hi);
+        h[0][j] = __builtin_bit_cast(unsigned short, hi);
+        h[1][j] = __builtin_bit_cast(unsigned short, lo);
+    }
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+        uint4 w;
+        w.x = h[pc][0] | ((unsigned)h[pc][1] << 16); w.y = h[pc][2] | ((unsigned)h[pc][3] << 16);
+        w.z = h[pc][4] | ((unsigned)h[pc][5] << 16); w.w = h[pc][6] | ((unsigned)h[pc][7] << 16);
+        img[row * 16 + ((pc * 8 + slot) ^ (row & 15))] = w;
+    }
+}
+
+// partner image: `rows` channel rows (a multiple of 32) of 256 B, global -> LDS by DMA, 4 rows per wave-instruction;
+// LDS slot j of row c receives source slot j ^ (c & 15)
+__device__ __forceinline__ void stage_partner(const uint4* __restrict__ src, uint4* img, int rows, int wave, int lane)
+{
+    for (int r4 = wave; r4 * 4 < rows; r4 += 4) {
+        const int row = r4 * 4 + (lane >> 4);
+        glds16(src + row * 16 + ((lane & 15) ^ (row & 15)), img + r4 * 64);
+    }
+}
+
+// d(out) window of the 8x8 query tile at (ty0, tx0), level l.  The loads of a round (24 channels per thread) are all
+// issued before `between()` runs and are written to LDS after it.  BYQ: D[q][rd2 | 1], else D[ch][64].
+template <bool BYQ, class F>
+__device__ __forceinline__ void load_dtile(const AltBwdArgs& p, float* D, int b, int l, int ty0, int tx0, int rd2, F between)
+{
+    const size_t P = (size_t)p.H * p.W;
+    const int q = threadIdx.x & 63, w = threadIdx.x >> 6, gy = ty0 + (q >> 3), gx = tx0 + (q & 7);
+    const bool valid = gy < p.H && gx < p.W;
+    const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P + (valid ? (size_t)gy * p.W + gx : 0);
+    const int ldq = rd2 | 1;
+    int c0 = w;                                              // the first round always runs: between() holds a barrier
+    do {
+        float v[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) v[j] = src[(size_t)min(c0 + 4 * j, rd2 - 1) * P];
+        if (c0 == w) between();
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const int ch = c0 + 4 * j;
+            if (ch < rd2) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? v[j] : 0.f;
+        }
+    } while ((c0 += 96) < rd2);
+}
+
+// G image for an OWNED QUERY tile: row = query, k = target of the partner tile at (ty0, tx0) (level coordinates).
+// thread = (query tid & 63, target rows 2 * wave, 2 * wave + 1); D[ch][64].
+__device__ __forceinline__ void make_g_by_query(const TileQ& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
+{
+    const int q = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wx0 = sh.wx0[q], wy0 = sh.wy0[q];
+    const float fx = sh.fx[q], fy = sh.fy[q];
+    const int txs = tx0 - wx0;                               // tap column of the tile's first target column
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+        const int uy = 2 * wave + rr, ty = ty0 + uy - wy0;   // tap row
+        const bool oky0 = (unsigned)ty < (unsigned)rd, oky1 = (unsigned)(ty - 1) < (unsigned)rd;
+        const bool live = (oky0 || oky1) && txs + 7 >= 0 && txs - 1 < rd;
+        float g[8];
+        if (__ballot(live) == 0) {                           // wave-uniform: no query of the tile has a tap in this row
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = 0.f;
+        } else {
+            const int r0 = min(max(ty, 0), rd - 1), r1 = min(max(ty - 1, 0), rd - 1);
+            float E[9];                                      // E[i]: the window column txs - 1 + i, blended vertically
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int a = txs - 1 + i;
+                const bool okx = (unsigned)a < (unsigned)rd;
+                const int base = min(max(a, 0), rd - 1) * rd;
+                const float d0 = D[(base + r0) * 64 + q], d1 = D[(base + r1) * 64 + q];
+                E[i] = ((okx && oky0) ? d0 : 0.f) * (1.f - fy) + ((okx && oky1) ? d1 : 0.f) * fy;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = (E[i + 1] * (1.f - fx) + E[i] * fx) * sg;
+        }
+        store_g(Aimg, q, uy, g);
+    }
+}
+
+// G image for an OWNED TARGET tile at (ty0, tx0): row = target, k = query of the partner tile.
+// thread = (target tid & 63, query rows 2 * wave, 2 * wave + 1); D[q][rd2 | 1].
+__device__ __forceinline__ void make_g_by_target(const TileQ& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
+{
+    const int u = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int X = tx0 + (u & 7), Y = ty0 + (u >> 3), ldq = (rd * rd) | 1;
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+        const int qy = 2 * wave + rr;
+        float g[8];
+#pragma unroll
+        for (int qx = 0; qx < 8; ++qx) {
+            const int q = qy * 8 + qx;
+            const int tx = X - sh.wx0[q], ty = Y - sh.wy0[q];
+            const float fx = sh.fx[q], fy = sh.fy[q];
+            const bool okx0 = (unsigned)tx < (unsigned)rd, okx1 = (unsigned)(tx - 1) < (unsigned)rd;
+            const bool oky0 = (unsigned)ty < (unsigned)rd, oky1 = (unsigned)(ty - 1) < (unsigned)rd;
+            const int a0 = min(max(tx, 0), rd - 1) * rd, a1 = min(max(tx - 1, 0), rd - 1) * rd;
+            const int b0 = min(max(ty, 0), rd - 1), b1 = min(max(ty - 1, 0), rd - 1);
+            const float* Dq = D + q * ldq;
+            const float d00 = Dq[a0 + b0], d10 = Dq[a1 + b0], d01 = Dq[a0 + b1], d11 = Dq[a1 + b1];
+            const float e0 = ((okx0 && oky0) ? d00 : 0.f) * (1.f - fy) + ((okx0 && oky1) ? d01 : 0.f) * fy;
+            const float e1 = ((okx1 && oky0) ? d10 : 0.f) * (1.f - fy) + ((okx1 && oky1) ? d11 : 0.f) * fy;
+            g[qx] = (e0 * (1.f - fx) + e1 * fx) * sg;
+        }
+        store_g(Aimg, u, qy, g);
+    }
+}
+
+// acc[j] (rows 32 mb .. + 31 of the G image x channels 32 (nb0 + 2 j) .. + 31 of the partner image) += G * partner, K = 64
+__device__ __forceinline__ void mfma_step(const uint4* Aimg, const uint4* Bimg, v16f (&acc)[NCB / 2], int mb, int nb0,
+                                          int ncb, int l31, int kh)
+{
+    const int key = l31 & 15;
+    const uint4* arow = Aimg + (mb * 32 + l31) * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, arow[(2 * s + kh) ^ key]);
+        const f16x8 al = __builtin_bit_cast(f16x8, arow[(8 + 2 * s + kh) ^ key]);
+        f16x8 bh[NCB / 2], bl[NCB / 2];
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j)
+            if (nb0 + 2 * j < ncb) {
+                const uint4* brow = Bimg + ((nb0 + 2 * j) * 32 + l31) * 16;
+                bh[j] = __builtin_bit_cast(f16x8, brow[(2 * s + kh) ^ key]);
+                bl[j] = __builtin_bit_cast(f16x8, brow[(8 + 2 * s + kh) ^ key]);
+            }
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j)
+            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j)
+            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j)
+            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid: seg[L] workgroups (see AltBwdArgs::seg), block 256 = 4 waves; wave w: row block w & 1, column blocks (w >> 1) + 2 j
+__global__ __launch_bounds__(256, 2)
+void alt_bwd_kernel(AltBwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    __shared__ BwdSh sh;
+    uint4* Aimg = smem;
+    uint4* Bimg = smem + IMG_A;
+    float* D = (float*)(smem + IMG_A + IMG_B);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = wave & 1, nb0 = wave >> 1;
+    const int rd = 2 * p.r + 1, rd2 = rd * rd;
+    const int eg = range_exp16(wave_max128(fmaxf(p.dmax[lane], p.dmax[lane + 64])));
+    const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
+    const int e2 = range_exp16(wave_max128(fmaxf(p.maxpart[MAXPARTS16 + lane], p.maxpart[MAXPARTS16 + lane + 64])));
+    const float sg = ldexpf(1.0f, eg);
+    const size_t P = (size_t)p.H * p.W;
+    const int wg = blockIdx.x;
+
+    v16f acc[NCB / 2];
+#pragma unroll
+    for (int j = 0; j < NCB / 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    if (wg < p.seg[0]) {
+        // ---------------- d(fmap1): owner = query tile, partners = target tiles of every level ----------------
+        const int g = wg % p.ngroups, rest = wg / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
+        const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
+        Tile16 t;
+        t.b = b; t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
+        for (int l = 0; l < p.L; ++l) {
+            t.l = l;
+            __syncthreads();                                 // the previous level's D and window table are no longer read
+            load_dtile<false>(p, D, b, l, t.ty0, t.tx0, rd2, [&] { tile_level_setup(p, sh, t); });
+            __syncthreads();
+            if (t.U == 0) continue;
+            const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
+            const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * CG) * 16;
+            for (int ty = t.ymin >> 3; ty <= (t.ymin + t.bh - 1) >> 3; ++ty)
+                for (int tx = t.xmin >> 3; tx <= (t.xmin + t.bw - 1) >> 3; ++tx) {
+                    stage_partner(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, Bimg, ncb * 32, wave, lane);
+                    make_g_by_query(sh, D, Aimg, ty * 8, tx * 8, rd, sg);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    mfma_step(Aimg, Bimg, acc, mb, nb0, ncb, l31, kh);
+                    __syncthreads();                         // images are free again
+                }
+        }
+        const float unscale = ldexpf(1.0f, -(eg + e2));
+        float* __restrict__ out = p.df1 + (size_t)b * P * p.C;
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j) {
+            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
+            if (nb0 + 2 * j < ncb && c < p.C) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pix = sh.qpix[mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh];
+                    if (pix >= 0) out[(size_t)pix * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---------------- d(fmap2_l): owner = target tile, partners = query tiles whose windows touch it ----------------
+    int l = 0;
+    while (l + 1 < p.L && wg >= p.seg[l + 1]) ++l;
+    int idx = wg - p.seg[l];
+    const int g = idx % p.ngroups; idx /= p.ngroups;
+    const int nsplit = p.nsplit[l];
+    const int s = idx % nsplit; idx /= nsplit;
+    const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
+    const int tt = idx % ttiles, b = idx / ttiles;
+    const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
+    const int ty0 = (tt / ttx) * 8, tx0 = (tt % ttx) * 8;
+    const int4* __restrict__ boxes = p.boxes + ((size_t)b * p.L + l) * p.qtiles;
+    const uint4* __restrict__ f1b = p.f1t + ((size_t)b * p.qtiles * p.Cp + g * CG) * 16;
+
+    auto touches = [&](int e) {
+        const int4 bx = boxes[min(e, p.qtiles - 1)];
+        return e < p.qtiles && bx.x <= tx0 + 7 && bx.y >= tx0 && bx.z <= ty0 + 7 && bx.w >= ty0;
+    };
+    int n_touch = 0;
+    for (int base = 0; base < p.qtiles; base += 256) n_touch += __syncthreads_count(touches(base + tid));
+    const int lo = (int)((long long)s * n_touch / nsplit), hi = (int)((long long)(s + 1) * n_touch / nsplit);
+
+    Tile16 t;
+    t.b = b; t.l = l;
+    int pos = 0;
+    for (int base = 0; base < p.qtiles && pos < hi; base += 256) {
+        const bool flag = touches(base + tid);
+        const unsigned long long mask = __ballot(flag);
+        if (lane == 0) sh.wc[wave] = __popcll(mask);
+        __syncthreads();
+        int before = 0, chunk_n = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int n = sh.wc[w]; before += w < wave ? n : 0; chunk_n += n; }
+        if (flag) sh.list[before + __popcll(mask & ((1ull << lane) - 1))] = base + tid;
+        __syncthreads();
+        for (int i = max(lo - pos, 0); i < min(hi - pos, chunk_n); ++i) {
+            const int qt = sh.list[i];
+            t.ty0 = (qt / p.qtx) * QH; t.tx0 = (qt % p.qtx) * QW;
+            __syncthreads();                                 // the previous step's images, D and window table are free
+            stage_partner(f1b + (size_t)qt * p.Cp * 16, Bimg, ncb * 32, wave, lane);
+            load_dtile<true>(p, D, b, l, t.ty0, t.tx0, rd2, [&] { tile_level_setup(p, sh, t); });
+            __syncthreads();
+            make_g_by_target(sh, D, Aimg, ty0, tx0, rd, sg);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            mfma_step(Aimg, Bimg, acc, mb, nb0, ncb, l31, kh);
+        }
+        pos += chunk_n;
+        __syncthreads();                                     // list / counts are rewritten by the next round
+    }
+
+    const int Hl = p.hl[l], Wl = p.wl[l];
+    if (nsplit == 1) {
+        const float unscale = ldexpf(1.0f, -(eg + e1));
+        float* __restrict__ out = p.df2[l] + (size_t)b * Hl * Wl * p.C;
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j) {
+            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
+            if (nb0 + 2 * j < ncb && c < p.C) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int u = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    const int Y = ty0 + (u >> 3), X = tx0 + (u & 7);
+                    if (Y < Hl && X < Wl) out[((size_t)Y * Wl + X) * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
+                }
+            }
+        }
+    } else {
+        float* __restrict__ out = p.partial + p.poff[l] + ((((size_t)b * ttiles + tt) * nsplit + s) * TQ) * p.Cp;
+#pragma unroll
+        for (int j = 0; j < NCB / 2; ++j) {
+            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
+            if (nb0 + 2 * j < ncb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int u = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    out[(size_t)u * p.Cp + c] = acc[j][i];
+                }
+            }
+        }
+    }
+}
+
+// d(fmap2_l) of the split levels: partial tiles added in split order.  grid (ceil(max_l B*H_l*W_l*Cp/4 / 256), L)
+__global__ __launch_bounds__(256)
+void alt_bwd_reduce_kernel(AltBwdArgs p)
+{
+    const int lane = threadIdx.x & 63, l = blockIdx.y;
+    const int eg = range_exp16(wave_max128(fmaxf(p.dmax[lane], p.dmax[lane + 64])));
+    const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
+    const int nsplit = p.nsplit[l];
+    if (nsplit <= 1) return;
+    const int Hl = p.hl[l], Wl = p.wl[l], HWl = Hl * Wl, c4n = p.Cp >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.B * HWl * c4n) return;
+    const int c4 = (int)(idx % c4n), pix = (int)((idx / c4n) % HWl), b = (int)(idx / ((long long)c4n * HWl));
+    const int Y = pix / Wl, X = pix - Y * Wl, ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
+    const int tt = (Y >> 3) * ttx + (X >> 3), u = (Y & 7) * 8 + (X & 7);
+    const float4* __restrict__ src = (const float4*)(p.partial + p.poff[l]) + ((((size_t)b * ttiles + tt) * nsplit) * TQ + u) * c4n + c4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 v = src[(size_t)s * TQ * c4n];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const float unscale = ldexpf(1.0f, -(eg + e1));
+    float* __restrict__ out = p.df2[l] + ((size_t)b * HWl + pix) * p.C + 4 * c4;
+    const float r[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * c4 + j < p.C) out[j] = (r[j] * unscale) / p.sqrt_c;
+}
+
+struct BwdPlan {
+    int Cp, qtx, qtiles, ngroups;
+    int nsplit[RAFTCORR_MAX_LEVELS], ttiles[RAFTCORR_MAX_LEVELS], seg[RAFTCORR_MAX_LEVELS + 1];
+    size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
+    size_t off_boxes, off_partial, bytes;
+    bool any_split;
+};
+
+BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
+{
+    BwdPlan pl = {};
+    pl.Cp = (C + 31) / 32 * 32;
+    pl.qtx = (W + QW - 1) / QW;
+    pl.qtiles = pl.qtx * ((H + QH - 1) / QH);
+    pl.ngroups = (pl.Cp + CG - 1) / CG;
+    pl.seg[0] = B * pl.qtiles * pl.ngroups;
+    size_t pf = 0;
+    for (int l = 0; l < L; ++l) {
+        const int hl = H >> l, wl = W >> l;
+        pl.ttiles[l] = ((wl + 7) / 8) * ((hl + 7) / 8);
+        // query tiles that touch one target tile when the flow is smooth: ((8 + 2r + 2) * 2^l / 8 + 1)^2
+        const long long side = (((long long)(8 + 2 * r + 2) << l) >> 3) + 1;
+        const long long est = std::min<long long>(pl.qtiles, side * side);
+        pl.nsplit[l] = (int)std::min<long long>(MAXSPLIT, std::max<long long>(1, (est + 11) / 12));
+        if (l == 0) pl.nsplit[l] = 1;
+        if (l + 1 <= L) pl.seg[l + 1] = pl.seg[l] + B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups;
+        pl.poff[l] = pf;
+        if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
+    }
+    pl.off_boxes = 512;                                      // [0, 512): partial maxima of |dout|
+    pl.off_partial = (pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles + 255) / 256 * 256;
+    pl.bytes = pl.off_partial + pf * sizeof(float);
+    return pl;
+}
+
+}  // namespace
+
+size_t alt_tiles_bytes(int B, int C, int H, int W)
+{
+    const size_t Cp = (size_t)(C + 31) / 32 * 32;
+    return (size_t)B * ((W + 7) / 8) * ((H + 7) / 8) * Cp * 256;
+}
+
+int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s)
+{
+    const int Cp = (C + 31) / 32 * 32, tiles = ((W + 7) / 8) * ((H + 7) / 8);
+    hipLaunchKernelGGL(alt_pack_tiles_kernel, dim3(tiles, Cp / 32, B), dim3(256), 0, s, fmap, (uint4*)packed, C, Cp, H, W, maxpart);
+    return check_launch("alt_pack_tiles_kernel");
+}
+
+size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r)
+{
+    return make_plan(B, H, W, C, L, r).bytes;
+}
+
+int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
+                            int r, const float* coords, const float* dout, float* df1, float* const* df2,
+                            void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: radius %d > 7", r);
+    const BwdPlan pl = make_plan(B, H, W, C, L, r);
+    if (!workspace || workspace_bytes < pl.bytes)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace of %zu bytes needed, %zu given", pl.bytes, workspace_bytes);
+    if (((uintptr_t)workspace & 255) != 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace must be 256-byte aligned");
+    if ((long long)pl.seg[L] <= 0 || (size_t)B * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
+    AltBwdArgs a = {};
+    a.f1t = (const uint4*)f1t;
+    for (int l = 0; l < L; ++l) {
+        a.f2t[l] = (const uint4*)f2t[l]; a.hl[l] = H >> l; a.wl[l] = W >> l; a.df2[l] = df2[l];
+        a.poff[l] = (long long)pl.poff[l]; a.nsplit[l] = pl.nsplit[l];
+    }
+    for (int l = 0; l <= L; ++l) a.seg[l] = pl.seg[l];
+    a.coords = coords; a.dout = dout; a.maxpart = maxpart; a.df1 = df1;
+    a.dmax = (const float*)workspace;
+    a.boxes = (int4*)((char*)workspace + pl.off_boxes);
+    a.partial = (float*)((char*)workspace + pl.off_partial);
+    a.B = B; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
+    a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups;
+    a.sqrt_c = sqrtf((float)C);
+    const int rd2 = (2 * r + 1) * (2 * r + 1);
+    int rc = launch_maxabs1(dout, (size_t)B * L * rd2 * H * W, (float*)workspace, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(alt_boxes_kernel, dim3(B * L * pl.qtiles), dim3(64), 0, s, a);
+    rc = check_launch("alt_boxes_kernel");
+    if (rc) return rc;
+    const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * (rd2 + 1) * sizeof(float);
+    static thread_local bool allowed[64] = {};               // > 64 KiB of dynamic LDS: opt in once per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && !allowed[dev & 63]) {
+        e = hipFuncSetAttribute((const void*)alt_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (e == hipSuccess) allowed[dev & 63] = true;
+    }
+    if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_lookup_bwd: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(alt_bwd_kernel, dim3(pl.seg[L]), dim3(256), sm, s, a);
+    rc = check_launch("alt_bwd_kernel");
+    if (rc || !pl.any_split) return rc;
+    size_t most = 0;
+    for (int l = 0; l < L; ++l)
+        if (pl.nsplit[l] > 1) most = std::max(most, (size_t)B * (H >> l) * (W >> l) * (pl.Cp / 4));
+    hipLaunchKernelGGL(alt_bwd_reduce_kernel, dim3((unsigned)((most + 255) / 256), L), dim3(256), 0, s, a);
+    return check_launch("alt_bwd_reduce_kernel");
+}
+
+}  // namespace raftcorr

@@ -8,6 +8,33 @@ namespace raftcorr {
 namespace {
 
 constexpr int QW = 8, QH = 8, TQ = QW * QH;       // query tile
+constexpr int MAXPARTS16 = 128;                   // partial maxima per map (corr_maxabs_kernel, build_pyramid.hip)
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wave_max128(float m)       // m: max of this lane's two partial maxima
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+// power-of-two factor that maps max|x| into [2^14, 2^15) (as build_pyramid.hip:range_exponent)
+__device__ __forceinline__ int range_exp16(float m)
+{
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);
+    return 15 - e;
+}
+
+// direct-to-LDS load, 64 lanes x 16 B: per-lane global source, LDS destination = chunk base + lane * 16
+__device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_chunk)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
+}
 
 struct TileQ {
     int wx0[TQ], wy0[TQ];                         // window origin (x0 - r, y0 - r) per query
@@ -24,7 +51,6 @@ struct Tile16 {
     int xmin, ymin, bw, bh, U;
 };
 
-// queries' window origins + the bounding box of their in-level parts (wave 0: one lane per query)
 // window origins of the tile's queries at level t.l + the bounding box of their in-level parts (wave 0: one lane
 // per query).  t.b, t.l, t.ty0, t.tx0 must be set; contains a barrier (every thread of the workgroup calls it).
 template <class Args>

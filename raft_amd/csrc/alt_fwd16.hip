@@ -36,10 +36,6 @@ constexpr int NBW = UP / 64;                      // column blocks per wave
 constexpr int STG = (TQ + UP) * 8;                // uint4 slots per staging buffer: 64 query rows + UP target rows of 128 B
 constexpr int KC = 32;                            // channels per staged chunk = one 128-byte line per pixel
 constexpr int LDS_S = UP + 1;                     // S[q][u] row stride (odd: the per-query gathers are conflict-free)
-constexpr int MAXPARTS16 = 128;                   // partial maxima per map (corr_maxabs_kernel, build_pyramid.hip)
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct AltFwdArgs {
     const uint4* f1p;                             // packed fmap1: [B][H*W][Cp/32][8 slots of 16 B]
@@ -56,22 +52,6 @@ struct AltFwdArgs {
 struct TileSh : TileQ {
     int toff[UP];                                 // pixel index of the pass' box targets in the level, -1 beyond the box
 };
-
-__device__ __forceinline__ float wave_max128(float m)       // m: max of this lane's two partial maxima
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return m;
-}
-
-// power-of-two factor that maps max|x| into [2^14, 2^15) (as build_pyramid.hip:range_exponent)
-__device__ __forceinline__ int range_exp16(float m)
-{
-    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
-    int e;
-    frexpf(m, &e);
-    return 15 - e;
-}
 
 // ---------------------------------------------------------------------------------------------
 // pack: (B, C, HW) fp32 NCHW -> [B][HW][Cp/32][piece 2][32 ch] fp16, scaled.  grid (ceil(HW/256), Cp/8, B)
@@ -102,14 +82,6 @@ void alt_pack16_kernel(const float* __restrict__ f, uint4* __restrict__ packed, 
         w.z = h[pc][4] | ((unsigned)h[pc][5] << 16); w.w = h[pc][6] | ((unsigned)h[pc][7] << 16);
         dst[pc * 4] = w;                                     // slot = piece * 4 + (channel % 32) / 8
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_chunk)
-{
-    // 64 lanes x 16 B: per-lane global source, LDS destination = chunk base + lane * 16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -483,16 +483,4 @@ int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, 
     return run_bwd(a, true, "alt_backward", s);
 }
 
-// ---- all levels fused: backward of AlternateCorrBlock.__call__ (forward: alt_fwd16.hip) -----------
-int launch_alt_lookup_bwd(const float* f1, const LevelSet& f2lv, int B, int H, int W, int C, int L,
-                          int r, const float* coords, const float* dout, float* df1,
-                          const LevelSet& df2lv, hipStream_t s)
-{
-    AltTileArgs a = {};
-    a.f1 = f1; a.f2 = f2lv; a.df2 = df2lv; a.coords = coords; a.dout = dout; a.df1 = df1;
-    a.B = B; a.Nc = 1; a.C = C; a.H = H; a.W = W; a.L = L; a.r = r;
-    a.planar = 1; a.level_scale = 1; a.out_div = sqrtf((float)C);
-    return run_bwd(a, false, "alt_lookup_bwd", s);
-}
-
 }  // namespace raftcorr

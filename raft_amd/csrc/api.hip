@@ -309,21 +309,49 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
                                    (hipStream_t)stream);
 }
 
-int raftcorr_alt_lookup_bwd(const float* fmap1, const float* const* fmap2_levels, int B, int H, int W,
-                            int C, int num_levels, int radius, const float* coords, const float* dout,
-                            float* dfmap1, float* const* dfmap2_levels, void* stream)
+int64_t raftcorr_alt_tiles_bytes(int B, int C, int H, int W)
+{
+    if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+    return (int64_t)alt_tiles_bytes(B, C, H, W);
+}
+
+int raftcorr_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* scale, void* packed,
+                            int64_t packed_bytes, void* stream)
+{
+    int rc = check_dims("alt_pack_tiles", B, H, W);
+    if (rc) return rc;
+    if (!fmap || !scale || !packed || C < 1) return fail(RAFTCORR_EINVAL, "alt_pack_tiles: bad argument");
+    if (packed_bytes < (int64_t)alt_tiles_bytes(B, C, H, W))
+        return fail(RAFTCORR_EINVAL, "alt_pack_tiles: packed buffer too small (%lld < %zu bytes)", (long long)packed_bytes,
+                    alt_tiles_bytes(B, C, H, W));
+    return launch_alt_pack_tiles(fmap, B, C, H, W, scale, packed, (hipStream_t)stream);
+}
+
+int64_t raftcorr_alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius)
+{
+    if (B < 1 || C < 1 || H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || radius < 0) return 0;
+    return (int64_t)alt_lookup_bwd_workspace_bytes(B, H, W, C, num_levels, radius);
+}
+
+int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels, const float* scales,
+                            int B, int H, int W, int C, int num_levels, int radius,
+                            const float* coords, const float* dout, float* dfmap1, float* const* dfmap2_levels,
+                            void* workspace, int64_t workspace_bytes, void* stream)
 {
     int rc = check_dims("alt_lookup_bwd", B, H, W);
     if (rc) return rc;
-    if (!fmap1 || !coords || !dout || !dfmap1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: null pointer");
+    if (!tiles1 || !tiles2_levels || !scales || !coords || !dout || !dfmap1 || !dfmap2_levels)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: null pointer");
     if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: C=%d radius=%d", C, radius);
-    LevelSet lv, dlv;
-    rc = make_levels("alt_lookup_bwd(fmap2)", fmap2_levels, H, W, num_levels, lv, false);
-    if (rc) return rc;
-    rc = make_levels("alt_lookup_bwd(dfmap2)", dfmap2_levels, H, W, num_levels, dlv, false);
-    if (rc) return rc;
-    return launch_alt_lookup_bwd(fmap1, lv, B, H, W, C, num_levels, radius, coords, dout, dfmap1, dlv,
-                                 (hipStream_t)stream);
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: level %d of a %d x %d map is empty", l, H, W);
+        if (!tiles2_levels[l] || !dfmap2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: level %d pointer is null", l);
+    }
+    return launch_alt_lookup_bwd16(tiles1, tiles2_levels, scales, B, H, W, C, num_levels, radius, coords, dout, dfmap1,
+                                   dfmap2_levels, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
+                                   (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -430,6 +430,13 @@ int launch_maxabs(const float* f1, const float* f2, size_t n, float* out, hipStr
     return check_launch("corr_maxabs_kernel");
 }
 
+// partial maxima of one array (out: [MAXPARTS]); the range pass of the on-the-fly backward's d(out)
+int launch_maxabs1(const float* x, size_t n, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 1), dim3(256), 0, s, x, x, n, out);
+    return check_launch("corr_maxabs_kernel");
+}
+
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
 {
     unsigned u = __float_as_uint(x);

@@ -522,6 +522,27 @@ def test_alt_equals_all_pairs_at_kitti_shape(dev):
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-5
 
 
+def test_on_the_fly_backward_is_bit_reproducible(dev):
+    """raftcorr_alt_lookup_bwd has one writer per gradient element and a fixed summation order (no atomics):
+    two runs on the same inputs must agree bit for bit, also with incoherent flow (long partner lists, split
+    levels).  VERDICT r1 item 3."""
+    from raft_amd import AlternateCorrBlock
+    rs = np.random.RandomState(5)
+    B, D, H, W, L, r = 2, 96, 47, 78, 4, 4
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    con = np.stack([xx, yy], 0)[None].astype(np.float32) + 6.0 * rs.randn(B, 2, H, W).astype(np.float32)
+    gn = rs.randn(B, L * 81, H, W).astype(np.float32)
+    grads = []
+    for _ in range(2):
+        f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+        AlternateCorrBlock(f1, f2, num_levels=L, radius=r)(_t(con, dev)).backward(_t(gn, dev))
+        grads.append((f1.grad.cpu().numpy(), f2.grad.cpu().numpy()))
+    assert np.array_equal(grads[0][0], grads[1][0])
+    assert np.array_equal(grads[0][1], grads[1][1])
+    assert np.isfinite(grads[0][0]).all() and np.abs(grads[0][1]).max() > 0
+
+
 def test_host_errors(dev):
     from raft_amd import CorrBlock
     f = torch.zeros(1, 8, 6, 6, device=dev)
