@@ -25,7 +25,7 @@
 //    (target tile, channel group, split s of the list of overlapping query tiles); level 0 stores directly, the
 //    coarser levels (few target tiles, each touched by hundreds of query tiles) write per-split partial tiles that a
 //    small second kernel adds in a fixed order.  The list comes from a table of per-(level, query tile) window
-//    bounding boxes (alt_boxes_kernel) and is walked in increasing tile order: the summation order never changes.
+//    bounding boxes (alt_windows_kernel) and is walked in increasing tile order: the summation order never changes.
 #include "common.h"
 #include "alt_common.h"
 #include <algorithm>
@@ -51,6 +51,7 @@ struct AltBwdArgs {
     float* df1;                                   // (B, H, W, C)
     float* df2[RAFTCORR_MAX_LEVELS];              // (B, H_l, W_l, C)
     int4* boxes;                                  // [B][L][qtiles]: (xmin, xmax, ymin, ymax) of the tile's windows at level l
+    int4* wins;                                   // [B][L][qtiles][64]: (x0 - r, y0 - r, bits of fx, bits of fy) per query
     float* partial;                               // d(fmap2) partial tiles of the split levels
     long long poff[RAFTCORR_MAX_LEVELS];          // level l's offset in `partial` (floats)
     int nsplit[RAFTCORR_MAX_LEVELS];
@@ -60,7 +61,9 @@ struct AltBwdArgs {
     float sqrt_c;
 };
 
-struct BwdSh : TileQ {
+struct BwdSh {
+    int wx0[TQ], wy0[TQ];                         // window origins of the step's 64 queries
+    float fx[TQ], fy[TQ];
     int list[256];
     int wc[4];
 };
@@ -104,9 +107,9 @@ void alt_pack_tiles_kernel(const float* __restrict__ f, uint4* __restrict__ pack
 }
 
 // ---------------------------------------------------------------------------------------------
-// window bounding boxes: grid B * L * qtiles, block 64
+// per (batch, level, query tile): the 64 windows (origin + fractions) and their bounding box.  grid B * L * qtiles, block 64
 __global__ __launch_bounds__(64)
-void alt_boxes_kernel(AltBwdArgs p)
+void alt_windows_kernel(AltBwdArgs p)
 {
     __shared__ TileQ sh;
     const int tile = blockIdx.x % p.qtiles, bl = blockIdx.x / p.qtiles;
@@ -114,7 +117,9 @@ void alt_boxes_kernel(AltBwdArgs p)
     t.l = bl % p.L; t.b = bl / p.L;
     t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
     tile_level_setup(p, sh, t);
-    if (threadIdx.x == 0) p.boxes[blockIdx.x] = make_int4(sh.box[0], sh.box[1], sh.box[2], sh.box[3]);
+    const int q = threadIdx.x;
+    p.wins[(size_t)blockIdx.x * TQ + q] = make_int4(sh.wx0[q], sh.wy0[q], __float_as_int(sh.fx[q]), __float_as_int(sh.fy[q]));
+    if (q == 0) p.boxes[blockIdx.x] = make_int4(sh.box[0], sh.box[1], sh.box[2], sh.box[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -144,39 +149,58 @@ __device__ __forceinline__ void store_g(uint4* img, int row, int slot, const flo
 // LDS slot j of row c receives source slot j ^ (c & 15)
 __device__ __forceinline__ void stage_partner(const uint4* __restrict__ src, uint4* img, int rows, int wave, int lane)
 {
+#if defined(RC_LAB_BWD_NODMA)
+    return;
+#endif
     for (int r4 = wave; r4 * 4 < rows; r4 += 4) {
         const int row = r4 * 4 + (lane >> 4);
         glds16(src + row * 16 + ((lane & 15) ^ (row & 15)), img + r4 * 64);
     }
 }
 
-// d(out) window of the 8x8 query tile at (ty0, tx0), level l.  The loads of a round (24 channels per thread) are all
-// issued before `between()` runs and are written to LDS after it.  BYQ: D[q][rd2 | 1], else D[ch][64].
-template <bool BYQ, class F>
-__device__ __forceinline__ void load_dtile(const AltBwdArgs& p, float* D, int b, int l, int ty0, int tx0, int rd2, F between)
+// d(out) window of the 8x8 query tile at (ty0, tx0), level l, in two halves so that the loads can fly under other
+// work: dtile_issue starts the loads of channels w, w + 4, .. (< 96) into v, dtile_commit writes them to LDS
+// (BYQ: D[q][rd2 | 1], else D[ch][64]) and fetches what a radius > 4 has beyond 96 channels.
+struct DTile {
+    float v[24];
+    int4 win;
+};
+
+__device__ __forceinline__ void dtile_issue(const AltBwdArgs& p, DTile& d, int b, int l, int qt, int rd2)
 {
     const size_t P = (size_t)p.H * p.W;
-    const int q = threadIdx.x & 63, w = threadIdx.x >> 6, gy = ty0 + (q >> 3), gx = tx0 + (q & 7);
+    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
     const bool valid = gy < p.H && gx < p.W;
     const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P + (valid ? (size_t)gy * p.W + gx : 0);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) d.v[j] = src[(size_t)min(w + 4 * j, rd2 - 1) * P];
+    d.win = p.wins[(((size_t)b * p.L + l) * p.qtiles + qt) * TQ + q];
+}
+
+template <bool BYQ>
+__device__ __forceinline__ void dtile_commit(const AltBwdArgs& p, const DTile& d, float* D, BwdSh& sh, int b, int l, int qt, int rd2)
+{
+    const size_t P = (size_t)p.H * p.W;
+    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
+    const bool valid = gy < p.H && gx < p.W;
     const int ldq = rd2 | 1;
-    int c0 = w;                                              // the first round always runs: between() holds a barrier
-    do {
-        float v[24];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) v[j] = src[(size_t)min(c0 + 4 * j, rd2 - 1) * P];
-        if (c0 == w) between();
-#pragma unroll
-        for (int j = 0; j < 24; ++j) {
-            const int ch = c0 + 4 * j;
-            if (ch < rd2) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? v[j] : 0.f;
-        }
-    } while ((c0 += 96) < rd2);
+    for (int j = 0; j < 24; ++j) {
+        const int ch = w + 4 * j;
+        if (ch < rd2) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? d.v[j] : 0.f;
+    }
+    if (w == 0) { sh.wx0[q] = d.win.x; sh.wy0[q] = d.win.y; sh.fx[q] = __int_as_float(d.win.z); sh.fy[q] = __int_as_float(d.win.w); }
+    if (rd2 > 96) {
+        const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P + (valid ? (size_t)gy * p.W + gx : 0);
+        for (int ch = 96 + w; ch < rd2; ch += 4) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? src[(size_t)ch * P] : 0.f;
+    }
 }
 
 // G image for an OWNED QUERY tile: row = query, k = target of the partner tile at (ty0, tx0) (level coordinates).
 // thread = (query tid & 63, target rows 2 * wave, 2 * wave + 1); D[ch][64].
-__device__ __forceinline__ void make_g_by_query(const TileQ& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
+__device__ __forceinline__ void make_g_by_query(const BwdSh& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
 {
     const int q = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wx0 = sh.wx0[q], wy0 = sh.wy0[q];
@@ -211,7 +235,7 @@ __device__ __forceinline__ void make_g_by_query(const TileQ& sh, const float* D,
 
 // G image for an OWNED TARGET tile at (ty0, tx0): row = target, k = query of the partner tile.
 // thread = (target tid & 63, query rows 2 * wave, 2 * wave + 1); D[q][rd2 | 1].
-__device__ __forceinline__ void make_g_by_target(const TileQ& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
+__device__ __forceinline__ void make_g_by_target(const BwdSh& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
 {
     const int u = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int X = tx0 + (u & 7), Y = ty0 + (u >> 3), ldq = (rd * rd) | 1;
@@ -238,9 +262,12 @@ __device__ __forceinline__ void make_g_by_target(const TileQ& sh, const float* D
     }
 }
 
-// acc[j] (rows 32 mb .. + 31 of the G image x channels 32 (nb0 + 2 j) .. + 31 of the partner image) += G * partner, K = 64
+// acc[j] (rows 32 mb .. + 31 of the G image x channels 32 (nb0 + 2 j) .. + 31 of the partner image) += G * partner, K = 64.
+// Unconditional on purpose: column blocks beyond the map's channels multiply whatever the image rows hold and are
+// never stored (a column of the product depends on its own column of the partner only); a wave-uniform `if` around
+// an MFMA makes hipcc copy whole accumulators between the two paths after every instruction.
 __device__ __forceinline__ void mfma_step(const uint4* Aimg, const uint4* Bimg, v16f (&acc)[NCB / 2], int mb, int nb0,
-                                          int ncb, int l31, int kh)
+                                          int l31, int kh)
 {
     const int key = l31 & 15;
     const uint4* arow = Aimg + (mb * 32 + l31) * 16;
@@ -250,21 +277,18 @@ __device__ __forceinline__ void mfma_step(const uint4* Aimg, const uint4* Bimg, 
         const f16x8 al = __builtin_bit_cast(f16x8, arow[(8 + 2 * s + kh) ^ key]);
         f16x8 bh[NCB / 2], bl[NCB / 2];
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j)
-            if (nb0 + 2 * j < ncb) {
-                const uint4* brow = Bimg + ((nb0 + 2 * j) * 32 + l31) * 16;
-                bh[j] = __builtin_bit_cast(f16x8, brow[(2 * s + kh) ^ key]);
-                bl[j] = __builtin_bit_cast(f16x8, brow[(8 + 2 * s + kh) ^ key]);
-            }
+        for (int j = 0; j < NCB / 2; ++j) {
+            const uint4* brow = Bimg + ((nb0 + 2 * j) * 32 + l31) * 16;
+            bh[j] = __builtin_bit_cast(f16x8, brow[(2 * s + kh) ^ key]);
+            bl[j] = __builtin_bit_cast(f16x8, brow[(8 + 2 * s + kh) ^ key]);
+        }
+        // small terms first; the column blocks take turns inside each term, so that no MFMA waits for the one before it
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j)
-            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NCB / 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j)
-            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NCB / 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j)
-            if (nb0 + 2 * j < ncb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NCB / 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
     }
 }
 
@@ -295,27 +319,37 @@ void alt_bwd_kernel(AltBwdArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+#if defined(RC_LAB_BWD_ONLY1)
+    if (wg >= p.seg[0]) return;
+#elif defined(RC_LAB_BWD_ONLY2)
+    if (wg < p.seg[0]) return;
+#endif
     if (wg < p.seg[0]) {
         // ---------------- d(fmap1): owner = query tile, partners = target tiles of every level ----------------
         const int g = wg % p.ngroups, rest = wg / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
         const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
-        Tile16 t;
-        t.b = b; t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
+        DTile dt;
+        dtile_issue(p, dt, b, 0, tile, rd2);
         for (int l = 0; l < p.L; ++l) {
-            t.l = l;
+            const int4 box = p.boxes[((size_t)b * p.L + l) * p.qtiles + tile];
             __syncthreads();                                 // the previous level's D and window table are no longer read
-            load_dtile<false>(p, D, b, l, t.ty0, t.tx0, rd2, [&] { tile_level_setup(p, sh, t); });
+            dtile_commit<false>(p, dt, D, sh, b, l, tile, rd2);
+            if (l + 1 < p.L) dtile_issue(p, dt, b, l + 1, tile, rd2);        // flies under this level's steps
             __syncthreads();
-            if (t.U == 0) continue;
+            if (box.x > box.y || box.z > box.w) continue;
             const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
             const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * CG) * 16;
-            for (int ty = t.ymin >> 3; ty <= (t.ymin + t.bh - 1) >> 3; ++ty)
-                for (int tx = t.xmin >> 3; tx <= (t.xmin + t.bw - 1) >> 3; ++tx) {
+            for (int ty = box.z >> 3; ty <= box.w >> 3; ++ty)
+                for (int tx = box.x >> 3; tx <= box.y >> 3; ++tx) {
                     stage_partner(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, Bimg, ncb * 32, wave, lane);
+#if !defined(RC_LAB_BWD_NOG)
                     make_g_by_query(sh, D, Aimg, ty * 8, tx * 8, rd, sg);
+#endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    mfma_step(Aimg, Bimg, acc, mb, nb0, ncb, l31, kh);
+#if !defined(RC_LAB_BWD_NOMFMA)
+                    mfma_step(Aimg, Bimg, acc, mb, nb0, l31, kh);
+#endif
                     __syncthreads();                         // images are free again
                 }
         }
@@ -327,8 +361,9 @@ void alt_bwd_kernel(AltBwdArgs p)
             if (nb0 + 2 * j < ncb && c < p.C) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int pix = sh.qpix[mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh];
-                    if (pix >= 0) out[(size_t)pix * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
+                    const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
+                    if (gy < p.H && gx < p.W) out[((size_t)gy * p.W + gx) * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
                 }
             }
         }
@@ -357,8 +392,9 @@ void alt_bwd_kernel(AltBwdArgs p)
     for (int base = 0; base < p.qtiles; base += 256) n_touch += __syncthreads_count(touches(base + tid));
     const int lo = (int)((long long)s * n_touch / nsplit), hi = (int)((long long)(s + 1) * n_touch / nsplit);
 
-    Tile16 t;
-    t.b = b; t.l = l;
+    // The d(out) tile and the windows of partner i + 1 are fetched into registers while step i runs; the partners are
+    // known one chunk of 256 table entries at a time, so the first step of a chunk waits for its own loads.
+    DTile dt;
     int pos = 0;
     for (int base = 0; base < p.qtiles && pos < hi; base += 256) {
         const bool flag = touches(base + tid);
@@ -370,17 +406,23 @@ void alt_bwd_kernel(AltBwdArgs p)
         for (int w = 0; w < 4; ++w) { const int n = sh.wc[w]; before += w < wave ? n : 0; chunk_n += n; }
         if (flag) sh.list[before + __popcll(mask & ((1ull << lane) - 1))] = base + tid;
         __syncthreads();
-        for (int i = max(lo - pos, 0); i < min(hi - pos, chunk_n); ++i) {
+        const int i0 = max(lo - pos, 0), i1 = min(hi - pos, chunk_n);
+        if (i0 < i1) dtile_issue(p, dt, b, l, sh.list[i0], rd2);
+        for (int i = i0; i < i1; ++i) {
             const int qt = sh.list[i];
-            t.ty0 = (qt / p.qtx) * QH; t.tx0 = (qt % p.qtx) * QW;
             __syncthreads();                                 // the previous step's images, D and window table are free
+            dtile_commit<true>(p, dt, D, sh, b, l, qt, rd2);
+            if (i + 1 < i1) dtile_issue(p, dt, b, l, sh.list[i + 1], rd2);
             stage_partner(f1b + (size_t)qt * p.Cp * 16, Bimg, ncb * 32, wave, lane);
-            load_dtile<true>(p, D, b, l, t.ty0, t.tx0, rd2, [&] { tile_level_setup(p, sh, t); });
             __syncthreads();
+#if !defined(RC_LAB_BWD_NOG)
             make_g_by_target(sh, D, Aimg, ty0, tx0, rd, sg);
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            mfma_step(Aimg, Bimg, acc, mb, nb0, ncb, l31, kh);
+#if !defined(RC_LAB_BWD_NOMFMA)
+            mfma_step(Aimg, Bimg, acc, mb, nb0, l31, kh);
+#endif
         }
         pos += chunk_n;
         __syncthreads();                                     // list / counts are rewritten by the next round
@@ -451,7 +493,7 @@ struct BwdPlan {
     int Cp, qtx, qtiles, ngroups;
     int nsplit[RAFTCORR_MAX_LEVELS], ttiles[RAFTCORR_MAX_LEVELS], seg[RAFTCORR_MAX_LEVELS + 1];
     size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
-    size_t off_boxes, off_partial, bytes;
+    size_t off_boxes, off_wins, off_partial, bytes;
     bool any_split;
 };
 
@@ -477,7 +519,8 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
         if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
     }
     pl.off_boxes = 512;                                      // [0, 512): partial maxima of |dout|
-    pl.off_partial = (pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles + 255) / 256 * 256;
+    pl.off_wins = (pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles + 255) / 256 * 256;
+    pl.off_partial = (pl.off_wins + sizeof(int4) * (size_t)B * L * pl.qtiles * TQ + 255) / 256 * 256;
     pl.bytes = pl.off_partial + pf * sizeof(float);
     return pl;
 }
@@ -523,6 +566,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     a.coords = coords; a.dout = dout; a.maxpart = maxpart; a.df1 = df1;
     a.dmax = (const float*)workspace;
     a.boxes = (int4*)((char*)workspace + pl.off_boxes);
+    a.wins = (int4*)((char*)workspace + pl.off_wins);
     a.partial = (float*)((char*)workspace + pl.off_partial);
     a.B = B; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
     a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups;
@@ -530,8 +574,8 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc = launch_maxabs1(dout, (size_t)B * L * rd2 * H * W, (float*)workspace, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(alt_boxes_kernel, dim3(B * L * pl.qtiles), dim3(64), 0, s, a);
-    rc = check_launch("alt_boxes_kernel");
+    hipLaunchKernelGGL(alt_windows_kernel, dim3(B * L * pl.qtiles), dim3(64), 0, s, a);
+    rc = check_launch("alt_windows_kernel");
     if (rc) return rc;
     const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * (rd2 + 1) * sizeof(float);
     static thread_local bool allowed[64] = {};               // > 64 KiB of dynamic LDS: opt in once per device

@@ -410,7 +410,17 @@ void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ 
     const float* __restrict__ x = blockIdx.y ? f2 : f1;
     float m = 0.f;
     const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;           // 16-byte loads when aligned
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)MAXPARTS * 256) {
+    constexpr size_t STRIDE = (size_t)MAXPARTS * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * STRIDE < n4; i += 4 * STRIDE) {                       // four loads in flight per thread
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((const float4*)x)[i + j * STRIDE];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+    }
+    for (; i < n4; i += STRIDE) {
         const float4 v = ((const float4*)x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
