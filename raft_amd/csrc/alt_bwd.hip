@@ -125,8 +125,8 @@ void alt_windows_kernel(AltBwdArgs p)
 // ---------------------------------------------------------------------------------------------
 // pieces of one step
 
-// 8 scaled gradients -> two fp16 pieces -> slots `slot` (hi) and 8 + slot (lo) of row `row` of the G image
-__device__ __forceinline__ void store_g(uint4* img, int row, int slot, const float (&g)[8])
+// 8 scaled gradients -> two fp16 pieces -> slots `slot` (hi) and 8 + slot (lo) of row `row` of the G image, XOR key
+__device__ __forceinline__ void store_g(uint4* img, int row, int slot, int key, const float (&g)[8])
 {
     unsigned short h[2][8];
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ void store_g(uint4* img, int row, int slot, const flo
         uint4 w;
         w.x = h[pc][0] | ((unsigned)h[pc][1] << 16); w.y = h[pc][2] | ((unsigned)h[pc][3] << 16);
         w.z = h[pc][4] | ((unsigned)h[pc][5] << 16); w.w = h[pc][6] | ((unsigned)h[pc][7] << 16);
-        img[row * 16 + ((pc * 8 + slot) ^ (row & 15))] = w;
+        img[row * 16 + ((pc * 8 + slot) ^ key)] = w;
     }
 }
 
@@ -200,6 +200,9 @@ __device__ __forceinline__ void dtile_commit(const AltBwdArgs& p, const DTile& d
 
 // G image for an OWNED QUERY tile: row = query, k = target of the partner tile at (ty0, tx0) (level coordinates).
 // thread = (query tid & 63, target rows 2 * wave, 2 * wave + 1); D[ch][64].
+// TR: the image is read back TRANSPOSED (ds_read_b64_tr_b16, rows q .. q + 3 at a time): slot key 4 * (q & 3) keeps those
+// four rows on different banks; row reads (ds_read_b128, 16 different rows at a time) want the key q & 15.
+template <bool TR>
 __device__ __forceinline__ void make_g_by_query(const BwdSh& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
 {
     const int q = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -229,36 +232,7 @@ __device__ __forceinline__ void make_g_by_query(const BwdSh& sh, const float* D,
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = (E[i + 1] * (1.f - fx) + E[i] * fx) * sg;
         }
-        store_g(Aimg, q, uy, g);
-    }
-}
-
-// G image for an OWNED TARGET tile at (ty0, tx0): row = target, k = query of the partner tile.
-// thread = (target tid & 63, query rows 2 * wave, 2 * wave + 1); D[q][rd2 | 1].
-__device__ __forceinline__ void make_g_by_target(const BwdSh& sh, const float* D, uint4* Aimg, int ty0, int tx0, int rd, float sg)
-{
-    const int u = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int X = tx0 + (u & 7), Y = ty0 + (u >> 3), ldq = (rd * rd) | 1;
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-        const int qy = 2 * wave + rr;
-        float g[8];
-#pragma unroll
-        for (int qx = 0; qx < 8; ++qx) {
-            const int q = qy * 8 + qx;
-            const int tx = X - sh.wx0[q], ty = Y - sh.wy0[q];
-            const float fx = sh.fx[q], fy = sh.fy[q];
-            const bool okx0 = (unsigned)tx < (unsigned)rd, okx1 = (unsigned)(tx - 1) < (unsigned)rd;
-            const bool oky0 = (unsigned)ty < (unsigned)rd, oky1 = (unsigned)(ty - 1) < (unsigned)rd;
-            const int a0 = min(max(tx, 0), rd - 1) * rd, a1 = min(max(tx - 1, 0), rd - 1) * rd;
-            const int b0 = min(max(ty, 0), rd - 1), b1 = min(max(ty - 1, 0), rd - 1);
-            const float* Dq = D + q * ldq;
-            const float d00 = Dq[a0 + b0], d10 = Dq[a1 + b0], d01 = Dq[a0 + b1], d11 = Dq[a1 + b1];
-            const float e0 = ((okx0 && oky0) ? d00 : 0.f) * (1.f - fy) + ((okx0 && oky1) ? d01 : 0.f) * fy;
-            const float e1 = ((okx1 && oky0) ? d10 : 0.f) * (1.f - fy) + ((okx1 && oky1) ? d11 : 0.f) * fy;
-            g[qx] = (e0 * (1.f - fx) + e1 * fx) * sg;
-        }
-        store_g(Aimg, u, qy, g);
+        store_g(Aimg, q, uy, TR ? 4 * (q & 3) : (q & 15), g);
     }
 }
 
@@ -266,15 +240,37 @@ __device__ __forceinline__ void make_g_by_target(const BwdSh& sh, const float* D
 // Unconditional on purpose: column blocks beyond the map's channels multiply whatever the image rows hold and are
 // never stored (a column of the product depends on its own column of the partner only); a wave-uniform `if` around
 // an MFMA makes hipcc copy whole accumulators between the two paths after every instruction.
+// TR: the G image is [k][row] (stored by make_g_by_query<true>) and its fragments come through transposed reads: a
+// 16-lane group fetches 4 image rows (k) x 16 columns and every lane receives one column; lane 4 qq + pp of a group
+// supplies the address of row qq, columns 4 pp .. 4 pp + 3.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <bool TR>
 __device__ __forceinline__ void mfma_step(const uint4* Aimg, const uint4* Bimg, v16f (&acc)[NCB / 2], int mb, int nb0,
                                           int l31, int kh)
 {
     const int key = l31 & 15;
     const uint4* arow = Aimg + (mb * 32 + l31) * 16;
+    // transposed reads: image row of this lane's address = 16 s + 8 kh + 4 r + qq; 16-byte slot = 4 mb + 2 gh + (pp >> 1)
+    const int qq = (l31 & 15) >> 2, pp = l31 & 3, gh = l31 >> 4;
+    const short* abase = (const short*)Aimg + (8 * kh + qq) * 128 + (pp & 1) * 4;
+    const int slot_hi = ((4 * mb + 2 * gh + (pp >> 1)) ^ (4 * qq)) * 8, slot_lo = ((8 + 4 * mb + 2 * gh + (pp >> 1)) ^ (4 * qq)) * 8;
+    auto tr = [](const short* a) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    };
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, arow[(2 * s + kh) ^ key]);
-        const f16x8 al = __builtin_bit_cast(f16x8, arow[(8 + 2 * s + kh) ^ key]);
+        f16x8 ah, al;
+        if (TR) {
+            const short* a = abase + s * 16 * 128;
+            const s16x4 h0 = tr(a + slot_hi), h1 = tr(a + 4 * 128 + slot_hi), l0 = tr(a + slot_lo), l1 = tr(a + 4 * 128 + slot_lo);
+            ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            al = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+        } else {
+            ah = __builtin_bit_cast(f16x8, arow[(2 * s + kh) ^ key]);
+            al = __builtin_bit_cast(f16x8, arow[(8 + 2 * s + kh) ^ key]);
+        }
         f16x8 bh[NCB / 2], bl[NCB / 2];
 #pragma unroll
         for (int j = 0; j < NCB / 2; ++j) {
@@ -343,12 +339,12 @@ void alt_bwd_kernel(AltBwdArgs p)
                 for (int tx = box.x >> 3; tx <= box.y >> 3; ++tx) {
                     stage_partner(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, Bimg, ncb * 32, wave, lane);
 #if !defined(RC_LAB_BWD_NOG)
-                    make_g_by_query(sh, D, Aimg, ty * 8, tx * 8, rd, sg);
+                    make_g_by_query<false>(sh, D, Aimg, ty * 8, tx * 8, rd, sg);
 #endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
 #if !defined(RC_LAB_BWD_NOMFMA)
-                    mfma_step(Aimg, Bimg, acc, mb, nb0, l31, kh);
+                    mfma_step<false>(Aimg, Bimg, acc, mb, nb0, l31, kh);
 #endif
                     __syncthreads();                         // images are free again
                 }
@@ -411,17 +407,17 @@ void alt_bwd_kernel(AltBwdArgs p)
         for (int i = i0; i < i1; ++i) {
             const int qt = sh.list[i];
             __syncthreads();                                 // the previous step's images, D and window table are free
-            dtile_commit<true>(p, dt, D, sh, b, l, qt, rd2);
+            dtile_commit<false>(p, dt, D, sh, b, l, qt, rd2);
             if (i + 1 < i1) dtile_issue(p, dt, b, l, sh.list[i + 1], rd2);
             stage_partner(f1b + (size_t)qt * p.Cp * 16, Bimg, ncb * 32, wave, lane);
             __syncthreads();
 #if !defined(RC_LAB_BWD_NOG)
-            make_g_by_target(sh, D, Aimg, ty0, tx0, rd, sg);
+            make_g_by_query<true>(sh, D, Aimg, ty0, tx0, rd, sg);
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #if !defined(RC_LAB_BWD_NOMFMA)
-            mfma_step(Aimg, Bimg, acc, mb, nb0, l31, kh);
+            mfma_step<true>(Aimg, Bimg, acc, mb, nb0, l31, kh);
 #endif
         }
         pos += chunk_n;
