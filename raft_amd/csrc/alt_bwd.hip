@@ -158,43 +158,43 @@ __device__ __forceinline__ void stage_partner(const uint4* __restrict__ src, uin
     }
 }
 
-// d(out) window of the 8x8 query tile at (ty0, tx0), level l, in two halves so that the loads can fly under other
-// work: dtile_issue starts the loads of channels w, w + 4, .. (< 96) into v, dtile_commit writes them to LDS
-// (BYQ: D[q][rd2 | 1], else D[ch][64]) and fetches what a radius > 4 has beyond 96 channels.
+// d(out) window of the 8x8 query tile qt, level l, in two halves so that the loads can fly under other work:
+// dtile_issue starts the loads of channels wave, wave + 4, .. (< 96) into v, dtile_commit writes them to LDS and
+// fetches what a radius > 4 has beyond 96 channels.
 struct DTile {
     float v[24];
     int4 win;
 };
 
-__device__ __forceinline__ void dtile_issue(const AltBwdArgs& p, DTile& d, int b, int l, int qt, int rd2)
+__device__ __forceinline__ void dtile_issue(const AltBwdArgs& p, DTile& d, int b, int l, int qt, int rd2, int wave)
 {
     const size_t P = (size_t)p.H * p.W;
-    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = threadIdx.x & 63;
     const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
-    const bool valid = gy < p.H && gx < p.W;
-    const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P + (valid ? (size_t)gy * p.W + gx : 0);
+    const unsigned pix = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;      // out-of-map queries: any address
+    const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P;         // wave-uniform: scalar base + lane offset
 #pragma unroll
-    for (int j = 0; j < 24; ++j) d.v[j] = src[(size_t)min(w + 4 * j, rd2 - 1) * P];
+    for (int j = 0; j < 24; ++j) d.v[j] = (src + (size_t)min(wave + 4 * j, rd2 - 1) * P)[pix];
     d.win = p.wins[(((size_t)b * p.L + l) * p.qtiles + qt) * TQ + q];
 }
 
-template <bool BYQ>
-__device__ __forceinline__ void dtile_commit(const AltBwdArgs& p, const DTile& d, float* D, BwdSh& sh, int b, int l, int qt, int rd2)
+// D[ch][64]; room for max(rd2, 96) channels, so the 24 values go out unconditionally.  Queries outside the map keep
+// whatever was loaded: their windows sit at -(1 << 24), every tap test fails and G is exactly zero.
+__device__ __forceinline__ void dtile_commit(const AltBwdArgs& p, const DTile& d, float* D, BwdSh& sh, int b, int l, int qt,
+                                             int rd2, int wave)
 {
-    const size_t P = (size_t)p.H * p.W;
-    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
-    const bool valid = gy < p.H && gx < p.W;
-    const int ldq = rd2 | 1;
+    const int q = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-        const int ch = w + 4 * j;
-        if (ch < rd2) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? d.v[j] : 0.f;
-    }
-    if (w == 0) { sh.wx0[q] = d.win.x; sh.wy0[q] = d.win.y; sh.fx[q] = __int_as_float(d.win.z); sh.fy[q] = __int_as_float(d.win.w); }
+    for (int j = 0; j < 24; ++j) D[(wave + 4 * j) * 64 + q] = d.v[j];
+    // every wave writes the (same) windows: a wave that never read its d.win would carry the pending load into the next
+    // step, where hipcc has to wait for ALL vector-memory traffic before it can reuse the registers
+    sh.wx0[q] = d.win.x; sh.wy0[q] = d.win.y; sh.fx[q] = __int_as_float(d.win.z); sh.fy[q] = __int_as_float(d.win.w);
     if (rd2 > 96) {
-        const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P + (valid ? (size_t)gy * p.W + gx : 0);
-        for (int ch = 96 + w; ch < rd2; ch += 4) D[BYQ ? q * ldq + ch : ch * 64 + q] = valid ? src[(size_t)ch * P] : 0.f;
+        const size_t P = (size_t)p.H * p.W;
+        const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
+        const unsigned pix = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;
+        const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P;
+        for (int ch = 96 + wave; ch < rd2; ch += 4) D[ch * 64 + q] = (src + (size_t)ch * P)[pix];
     }
 }
 
@@ -209,31 +209,38 @@ __device__ __forceinline__ void make_g_by_query(const BwdSh& sh, const float* D,
     const int wx0 = sh.wx0[q], wy0 = sh.wy0[q];
     const float fx = sh.fx[q], fy = sh.fy[q];
     const int txs = tx0 - wx0;                               // tap column of the tile's first target column
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-        const int uy = 2 * wave + rr, ty = ty0 + uy - wy0;   // tap row
-        const bool oky0 = (unsigned)ty < (unsigned)rd, oky1 = (unsigned)(ty - 1) < (unsigned)rd;
-        const bool live = (oky0 || oky1) && txs + 7 >= 0 && txs - 1 < rd;
-        float g[8];
-        if (__ballot(live) == 0) {                           // wave-uniform: no query of the tile has a tap in this row
+    const int uy = 2 * wave, ty = ty0 + uy - wy0;            // tap rows ty, ty + 1 <- d(out) window rows ty - 1, ty, ty + 1
+    const bool okm = (unsigned)(ty - 1) < (unsigned)rd, ok0 = (unsigned)ty < (unsigned)rd, okp = (unsigned)(ty + 1) < (unsigned)rd;
+    const int key = TR ? 4 * (q & 3) : (q & 15);
+    const bool live = (okm || ok0 || okp) && txs + 7 >= 0 && txs - 1 < rd;
+    float g0[8], g1[8];
+    if (__ballot(live) == 0) {                               // wave-uniform: no query of the tile has a tap in these rows
 #pragma unroll
-            for (int i = 0; i < 8; ++i) g[i] = 0.f;
-        } else {
-            const int r0 = min(max(ty, 0), rd - 1), r1 = min(max(ty - 1, 0), rd - 1);
-            float E[9];                                      // E[i]: the window column txs - 1 + i, blended vertically
+        for (int i = 0; i < 8; ++i) g0[i] = g1[i] = 0.f;
+    } else {
+        // vertical blend weights with the row validity folded in (an invalid row is read at a clamped position, times 0)
+        const float a0m = okm ? fy : 0.f, a00 = ok0 ? 1.f - fy : 0.f;            // tap row ty     = rows ty - 1, ty
+        const float a10 = ok0 ? fy : 0.f, a1p = okp ? 1.f - fy : 0.f;            // tap row ty + 1 = rows ty, ty + 1
+        const float* Dm = D + min(max(ty - 1, 0), rd - 1) * 64 + q;
+        const float* D0 = D + min(max(ty, 0), rd - 1) * 64 + q;
+        const float* Dp = D + min(max(ty + 1, 0), rd - 1) * 64 + q;
+        const float cx1 = (1.f - fx) * sg, cx0 = fx * sg;
+        float E0[9], E1[9];                                  // window column txs - 1 + i, blended vertically
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int a = txs - 1 + i;
-                const bool okx = (unsigned)a < (unsigned)rd;
-                const int base = min(max(a, 0), rd - 1) * rd;
-                const float d0 = D[(base + r0) * 64 + q], d1 = D[(base + r1) * 64 + q];
-                E[i] = ((okx && oky0) ? d0 : 0.f) * (1.f - fy) + ((okx && oky1) ? d1 : 0.f) * fy;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) g[i] = (E[i + 1] * (1.f - fx) + E[i] * fx) * sg;
+        for (int i = 0; i < 9; ++i) {
+            const int a = txs - 1 + i;
+            const bool okx = (unsigned)a < (unsigned)rd;
+            const int base = min(max(a, 0), rd - 1) * rd * 64;
+            const float dm = Dm[base], d0 = D0[base], dp = Dp[base];
+            const float e0 = dm * a0m + d0 * a00, e1 = d0 * a10 + dp * a1p;
+            E0[i] = okx ? e0 : 0.f;
+            E1[i] = okx ? e1 : 0.f;
         }
-        store_g(Aimg, q, uy, TR ? 4 * (q & 3) : (q & 15), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { g0[i] = E0[i + 1] * cx1 + E0[i] * cx0; g1[i] = E1[i + 1] * cx1 + E1[i] * cx0; }
     }
+    store_g(Aimg, q, uy, key, g0);
+    store_g(Aimg, q, uy + 1, key, g1);
 }
 
 // acc[j] (rows 32 mb .. + 31 of the G image x channels 32 (nb0 + 2 j) .. + 31 of the partner image) += G * partner, K = 64.
@@ -288,6 +295,36 @@ __device__ __forceinline__ void mfma_step(const uint4* Aimg, const uint4* Bimg, 
     }
 }
 
+// s_barrier without the fence of __syncthreads() (which waits for every outstanding vector-memory operation once an
+// LDS DMA is among them): LDS traffic of this wave done, then the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One step after the d(out) tile and the windows are in LDS: partner image by DMA, G image, product.  The LDS regions
+// are restrict-qualified parameters: after inlining, the DMA destination and the reads / writes of the other regions
+// carry distinct alias scopes, so hipcc does not wait for the DMA in front of the first LDS access of make_g (the
+// construction of alt_fwd16.hip and build_pyramid.hip).  `prefetch()` may start global loads (no LDS access) that
+// stay in flight over the step; `keep` = how many of them (vector-memory loads complete in order: waiting until only
+// `keep` are outstanding means the older DMA has landed).
+template <bool TR, class F>
+__device__ __forceinline__ void pair_step(const uint4* __restrict__ src, int rows, uint4* __restrict__ Bimg,
+                                          uint4* __restrict__ Aimg, const float* __restrict__ D, const BwdSh& sh,
+                                          int ty0, int tx0, int rd, float sg, v16f (&acc)[NCB / 2],
+                                          int mb, int nb0, int l31, int kh, int wave, int lane, bool keep25, F prefetch)
+{
+    stage_partner(src, Bimg, rows, wave, lane);
+    asm volatile("" ::: "memory");                           // the DMA stays older than the prefetch
+    prefetch();
+#if !defined(RC_LAB_BWD_NOG)
+    make_g_by_query<TR>(sh, D, Aimg, ty0, tx0, rd, sg);
+#endif
+    if (keep25) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+    else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+#if !defined(RC_LAB_BWD_NOMFMA)
+    mfma_step<TR>(Aimg, Bimg, acc, mb, nb0, l31, kh);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // grid: seg[L] workgroups (see AltBwdArgs::seg), block 256 = 4 waves; wave w: row block w & 1, column blocks (w >> 1) + 2 j
 __global__ __launch_bounds__(256, 2)
@@ -325,28 +362,21 @@ void alt_bwd_kernel(AltBwdArgs p)
         const int g = wg % p.ngroups, rest = wg / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
         const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
         DTile dt;
-        dtile_issue(p, dt, b, 0, tile, rd2);
+        dtile_issue(p, dt, b, 0, tile, rd2, wave);
         for (int l = 0; l < p.L; ++l) {
             const int4 box = p.boxes[((size_t)b * p.L + l) * p.qtiles + tile];
             __syncthreads();                                 // the previous level's D and window table are no longer read
-            dtile_commit<false>(p, dt, D, sh, b, l, tile, rd2);
-            if (l + 1 < p.L) dtile_issue(p, dt, b, l + 1, tile, rd2);        // flies under this level's steps
+            dtile_commit(p, dt, D, sh, b, l, tile, rd2, wave);
+            if (l + 1 < p.L) dtile_issue(p, dt, b, l + 1, tile, rd2, wave);        // flies under this level's steps
             __syncthreads();
             if (box.x > box.y || box.z > box.w) continue;
             const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
             const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * CG) * 16;
             for (int ty = box.z >> 3; ty <= box.w >> 3; ++ty)
                 for (int tx = box.x >> 3; tx <= box.y >> 3; ++tx) {
-                    stage_partner(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, Bimg, ncb * 32, wave, lane);
-#if !defined(RC_LAB_BWD_NOG)
-                    make_g_by_query<false>(sh, D, Aimg, ty * 8, tx * 8, rd, sg);
-#endif
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-#if !defined(RC_LAB_BWD_NOMFMA)
-                    mfma_step<false>(Aimg, Bimg, acc, mb, nb0, l31, kh);
-#endif
-                    __syncthreads();                         // images are free again
+                    pair_step<false>(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, ncb * 32, Bimg, Aimg, D, sh, ty * 8, tx * 8, rd, sg,
+                                     acc, mb, nb0, l31, kh, wave, lane, false, [] {});
+                    lds_barrier();                           // images are free again
                 }
         }
         const float unscale = ldexpf(1.0f, -(eg + e2));
@@ -403,22 +433,17 @@ void alt_bwd_kernel(AltBwdArgs p)
         if (flag) sh.list[before + __popcll(mask & ((1ull << lane) - 1))] = base + tid;
         __syncthreads();
         const int i0 = max(lo - pos, 0), i1 = min(hi - pos, chunk_n);
-        if (i0 < i1) dtile_issue(p, dt, b, l, sh.list[i0], rd2);
+        if (i0 < i1) dtile_issue(p, dt, b, l, sh.list[i0], rd2, wave);
         for (int i = i0; i < i1; ++i) {
             const int qt = sh.list[i];
-            __syncthreads();                                 // the previous step's images, D and window table are free
-            dtile_commit<false>(p, dt, D, sh, b, l, qt, rd2);
-            if (i + 1 < i1) dtile_issue(p, dt, b, l, sh.list[i + 1], rd2);
-            stage_partner(f1b + (size_t)qt * p.Cp * 16, Bimg, ncb * 32, wave, lane);
-            __syncthreads();
-#if !defined(RC_LAB_BWD_NOG)
-            make_g_by_query<true>(sh, D, Aimg, ty0, tx0, rd, sg);
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#if !defined(RC_LAB_BWD_NOMFMA)
-            mfma_step<true>(Aimg, Bimg, acc, mb, nb0, l31, kh);
-#endif
+            const bool more = i + 1 < i1;
+            const int qt_next = sh.list[more ? i + 1 : i];
+            lds_barrier();                                   // the previous step's images, D and window table are free
+            dtile_commit(p, dt, D, sh, b, l, qt, rd2, wave);
+            lds_barrier();
+            // the 25 loads of dtile_issue (24 channels + the windows) fly under this step and the start of the next
+            pair_step<true>(f1b + (size_t)qt * p.Cp * 16, ncb * 32, Bimg, Aimg, D, sh, ty0, tx0, rd, sg,
+                            acc, mb, nb0, l31, kh, wave, lane, more, [&] { if (more) dtile_issue(p, dt, b, l, qt_next, rd2, wave); });
         }
         pos += chunk_n;
         __syncthreads();                                     // list / counts are rewritten by the next round
@@ -573,7 +598,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     hipLaunchKernelGGL(alt_windows_kernel, dim3(B * L * pl.qtiles), dim3(64), 0, s, a);
     rc = check_launch("alt_windows_kernel");
     if (rc) return rc;
-    const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * (rd2 + 1) * sizeof(float);
+    const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * std::max(rd2, 96) * sizeof(float);
     static thread_local bool allowed[64] = {};               // > 64 KiB of dynamic LDS: opt in once per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
