@@ -158,7 +158,8 @@ int raftcorr_lookup_bwd(const float* const* levels, float* const* dlevels,
  * behind core/corr.py:26,59,61).  dlevels: accumulated pyramid gradient (padding cells must be
  * zero: zero the buffers once, lookups never touch padding); level 0 is used as scratch and is
  * CLOBBERED (it receives the folded level-0 gradient); levels 3.. are clobbered when L > 4.
- * dfmap1, dfmap2: (B,D,H,W) float32, overwritten. */
+ * dfmap1, dfmap2: (B,D,H,W) float32, overwritten.  No atomics: split-K partial products are kept in
+ * the workspace and added in a fixed order, so two calls on the same inputs give the same bits. */
 int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
                        int num_levels, float* const* dlevels,
                        float* dfmap1, float* dfmap2, void* workspace, int64_t workspace_bytes,

@@ -272,8 +272,11 @@ class CorrBlock:
     """All-pairs correlation volume + pooled pyramid + radius-r bilinear lookup.
     Drop-in for core/corr.py:12-61 (same constructor defaults: num_levels=2, radius=4).
 
-    precision (keyword, not in the reference) selects the arithmetic of the contraction; the
-    pyramid, the lookup and the backward pass are fp32 in every case:
+    precision (keyword, not in the reference) selects the arithmetic of the forward contraction; the
+    pyramid and the lookup are fp32 in every case, and the backward contractions run fp32-grade
+    (three bf16 pieces per operand, six products, fp32 accumulation; exact fp32 MFMA when the
+    operands are not 16-byte aligned) with a fixed summation order -- gradients are reproducible
+    bit for bit:
       "fp32"    (default) exact fp32 FMA chain on the fp32 matrix cores;
       "bf16x3"  operands split into three bfloat16 pieces, six bf16 MFMA products: fp32-grade
                 results (inside the 1e-5 parity bar by orders of magnitude), faster build;

@@ -1,5 +1,9 @@
-// Backward of the pyramid build: pooled-level gradients are folded down to level 0, then
-// two fp32-MFMA contractions give the feature gradients.
+// Backward of the pyramid build: pooled-level gradients are folded down to level 0, then two
+// contractions give the feature gradients.  Aligned operands (the normal case) run them on the
+// 16-bit matrix cores with every operand split into three bf16 pieces and six products
+// (gemm_bf16x3_kernel: fp32-grade); unaligned operands take the exact fp32-MFMA kernel
+// (gemm_f32_kernel).  Split-K partial products go to separate planes and are added in a fixed
+// order: the gradients are bit-reproducible.
 //
 // Replaces what autograd runs behind core/corr.py:26,59,61 in the reference
 // (avg_pool2d_backward x (L-1), the scale, and the two GEMMs of bmm's backward):
@@ -133,14 +137,17 @@ void corr_cols_scatter_back_kernel(const float* __restrict__ src, float* __restr
 // buffer loads (rows / k beyond the matrix read as zero), held in registers while the previous
 // tile is multiplied, and stored into LDS as [k][row] images whose reads and (transposed) writes
 // are both bank-conflict-free.  The K range can be split over gridDim.z (the feature-gradient
-// GEMMs have M = D = 256 only, i.e. few tiles and a long K): partial sums are then added with float
-// atomics into a zeroed C.
+// GEMMs have M = D = 256 only, i.e. few tiles and a long K): every split then stores its partial
+// product into its own plane of a workspace and gemm_reduce_kernel adds the planes in split order --
+// no atomics, no zero-fill, the same bits on every run.
 struct GemmArgs {
     const float* A; const float* B; float* C;
     int M, N, K;
     int lda, ldb, ldc;
     size_t sA, sB, sC;   // batch strides (elements)
     int ksplit, kper;    // gridDim.z = batch * ksplit; kper = K range per split (multiple of 32)
+    float* P;            // ksplit > 1: partial products [ksplit][batch][M][ldc]
+    int batch;
     int vecA, vecB;      // 16-byte loads legal (alignment + extents)
 };
 
@@ -183,7 +190,7 @@ void gemm_f32_kernel(GemmArgs p)
     const int M = p.M, N = p.N;
     const float* __restrict__ Ab = p.A + bz * p.sA;
     const float* __restrict__ Bb = p.B + bz * p.sB;
-    float* __restrict__ C = p.C + bz * p.sC;
+    float* __restrict__ C = p.ksplit > 1 ? p.P + ((size_t)ks * p.batch + bz) * p.sC : p.C + bz * p.sC;
     // buffer descriptors are re-based on every K tile (tile origin), so offsets stay small
     // whatever the matrix size; validity is decided per lane and spelled as an OOB offset
     auto desc = [](const float* base) {
@@ -277,8 +284,7 @@ void gemm_f32_kernel(GemmArgs p)
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
                 if (m < M && n < N) {
-                    if (p.ksplit > 1) atomicAdd(C + (size_t)m * p.ldc + n, acc[a][b][reg]);
-                    else C[(size_t)m * p.ldc + n] = acc[a][b][reg];
+                    C[(size_t)m * p.ldc + n] = acc[a][b][reg];
                 }
             }
         }
@@ -337,7 +343,7 @@ void gemm_bf16x3_kernel(GemmArgs p)
     const int M = p.M, N = p.N;
     const float* __restrict__ Ab = p.A + bz * p.sA;
     const float* __restrict__ Bb = p.B + bz * p.sB;
-    float* __restrict__ C = p.C + bz * p.sC;
+    float* __restrict__ C = p.ksplit > 1 ? p.P + ((size_t)ks * p.batch + bz) * p.sC : p.C + bz * p.sC;
     auto desc = [](const float* base) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
     };
@@ -463,34 +469,57 @@ void gemm_bf16x3_kernel(GemmArgs p)
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
                 if (m < M && n < N) {
-                    if (p.ksplit > 1) atomicAdd(C + (size_t)m * p.ldc + n, acc[a][b][reg]);
-                    else C[(size_t)m * p.ldc + n] = acc[a][b][reg];
+                    C[(size_t)m * p.ldc + n] = acc[a][b][reg];
                 }
             }
         }
 }
 
-// fills the launch-shape fields and runs one batched GEMM; C is zeroed first when K is split
+// C[i] = sum over the split planes, in split order.  grid: ceil(total / 4 / 256)
+__global__ __launch_bounds__(256)
+void gemm_reduce_kernel(const float* __restrict__ P, float* __restrict__ C, int ksplit, size_t total)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    if (i + 4 <= total && (((uintptr_t)P | (uintptr_t)C | (total * 4)) & 15) == 0) {
+        float4 sum = *(const float4*)(P + i);
+        for (int k = 1; k < ksplit; ++k) {
+            const float4 v = *(const float4*)(P + (size_t)k * total + i);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        *(float4*)(C + i) = sum;
+    } else {
+        for (size_t e = i; e < total && e < i + 4; ++e) {
+            float sum = P[e];
+            for (int k = 1; k < ksplit; ++k) sum += P[(size_t)k * total + e];
+            C[e] = sum;
+        }
+    }
+}
+
+// K splits of one batched GEMM: enough workgroups for the chip while every split keeps a K range of >= 256
+static int gemm_ksplit(int M, int N, int K, int batch)
+{
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+    int ksplit = 1;
+    while (tiles * ksplit < 512 && ksplit < 16 && K / (ksplit * 2) >= 256) ksplit *= 2;
+    return ksplit;
+}
+
+// fills the launch-shape fields and runs one batched GEMM (+ the reduction of its split planes); C must be
+// (M x ldc) per image, images back to back
 template <bool B_K_CONTIG>
-static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
+static int run_gemm(GemmArgs a, int batch, float* partial, const char* what, hipStream_t s)
 {
     if ((size_t)128 * std::max(a.lda, a.ldb) * 4 >= ((size_t)1 << 31))
         return fail(RAFTCORR_EUNSUPPORTED, "%s: leading dimension too large", what);
-    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-    int ksplit = 1;
-    while (tiles * ksplit < 512 && ksplit < 16 && a.K / (ksplit * 2) >= 256) ksplit *= 2;
+    const int ksplit = gemm_ksplit(a.M, a.N, a.K, batch);
     a.ksplit = ksplit;
     a.kper = (((a.K + ksplit - 1) / ksplit) + 31) / 32 * 32;
+    a.P = partial; a.batch = batch;
     a.vecA = (a.lda % 4 == 0) && (a.K % 4 == 0) && (((uintptr_t)a.A | (a.sA * 4)) % 16 == 0);
     a.vecB = (a.ldb % 4 == 0) && ((B_K_CONTIG ? a.K : a.N) % 4 == 0) && (((uintptr_t)a.B | (a.sB * 4)) % 16 == 0);
-    if (ksplit > 1) {
-        // C is (M x ldc) per image and fully owned by this GEMM
-        hipError_t e = hipSuccess;
-        if (a.sC == (size_t)a.M * a.ldc) e = hipMemsetAsync(a.C, 0, sizeof(float) * a.sC * batch, s);
-        else for (int b = 0; b < batch && e == hipSuccess; ++b)
-            e = hipMemsetAsync(a.C + b * a.sC, 0, sizeof(float) * (size_t)a.M * a.ldc, s);
-        if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
-    }
+    if (a.sC != (size_t)a.M * a.ldc) return fail(RAFTCORR_EINVAL, "%s: C images must be contiguous", what);
     const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit);
     bool split16 = a.vecA && a.vecB;                         // unaligned operands: the fp32-MFMA kernel
 #if defined(RC_LAB)                    // tools/ only: force the fp32-MFMA kernel
@@ -500,13 +529,21 @@ static int run_gemm(GemmArgs a, int batch, const char* what, hipStream_t s)
         hipLaunchKernelGGL(gemm_bf16x3_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
-    return check_launch(what);
+    int rc = check_launch(what);
+    if (rc || ksplit == 1) return rc;
+    const size_t total = a.sC * batch;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, partial, a.C, ksplit, total);
+    return check_launch("gemm_reduce_kernel");
 }
 
 size_t build_bwd_workspace_bytes(int B, int D, int H, int W)
 {
     const LevelGeom g0 = level_geom(H, W, 0);
-    return 2 * (size_t)B * D * g0.slab * sizeof(float);       // F2 in column order + dF2 in column order
+    const size_t S0 = (size_t)g0.slab, N = (size_t)H * W;
+    // F2 in column order + dF2 in column order + the split-K planes of the larger of the two GEMMs
+    const size_t p1 = gemm_ksplit(D, (int)N, (int)S0, B) > 1 ? gemm_ksplit(D, (int)N, (int)S0, B) * (size_t)B * D * N : 0;
+    const size_t p2 = gemm_ksplit(D, (int)S0, (int)N, B) > 1 ? gemm_ksplit(D, (int)S0, (int)N, B) * (size_t)B * D * S0 : 0;
+    return (2 * (size_t)B * D * S0 + std::max(p1, p2)) * sizeof(float);
 }
 
 static unsigned grid_for(size_t total, unsigned cap)
@@ -553,6 +590,7 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
 
     float* f2v = (float*)workspace;                 // [B][D][S0]
     float* df2v = f2v + (size_t)B * D * S0;         // [B][D][S0]
+    float* planes = df2v + (size_t)B * D * S0;      // split-K partial products
     hipLaunchKernelGGL(corr_cols_gather_kernel, dim3(grid_for((size_t)B * D * S0, 16384)), dim3(256), 0, s,
                        f2, f2v, B * D, H, W, (long long)S0);
     rc = check_launch("corr_cols_gather_kernel");
@@ -563,13 +601,13 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     a.A = f2v; a.B = dlv.ptr[0]; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
     a.lda = (int)S0; a.ldb = (int)S0; a.ldc = N;
     a.sA = (size_t)D * S0; a.sB = (size_t)N * S0; a.sC = (size_t)D * N;
-    rc = run_gemm<true>(a, B, "gemm_f32_kernel<dF1>", s);
+    rc = run_gemm<true>(a, B, planes, "gemm_f32_kernel<dF1>", s);
     if (rc) return rc;
     // dF2v[d][p] = sum_q F1[d][q] * dC0[q][p]      (B operand: n = p contiguous)
     a.A = f1; a.B = dlv.ptr[0]; a.C = df2v; a.M = D; a.N = (int)S0; a.K = N;
     a.lda = N; a.ldb = (int)S0; a.ldc = (int)S0;
     a.sA = (size_t)D * N; a.sB = (size_t)N * S0; a.sC = (size_t)D * S0;
-    rc = run_gemm<false>(a, B, "gemm_f32_kernel<dF2>", s);
+    rc = run_gemm<false>(a, B, planes, "gemm_f32_kernel<dF2>", s);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_cols_scatter_back_kernel, dim3(grid_for((size_t)B * D * N, 16384)), dim3(256), 0, s,
                        df2v, df2, B * D, H, W, dlv.g[0]);

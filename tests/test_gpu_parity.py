@@ -522,6 +522,33 @@ def test_alt_equals_all_pairs_at_kitti_shape(dev):
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-5
 
 
+def test_all_pairs_backward_is_bit_reproducible(dev):
+    """12 lookups + one backward pass through the shared gradient pyramid, twice: dfmap1 / dfmap2 must agree bit
+    for bit (lookup_bwd has one owner per cell, build_bwd adds its split-K planes in a fixed order).  Also the
+    unaligned-operand route (odd W: the exact fp32-MFMA GEMM) against the oracle."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(11)
+    for (B, D, H, W, nl) in ((2, 64, 40, 72, 12), (1, 32, 13, 19, 2)):
+        L, r = (4, 4) if H >= 16 else (2, 3)
+        f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        cons = [np.stack([xx, yy], 0)[None].astype(np.float32) + (1.0 + k) * rs.randn(B, 2, H, W).astype(np.float32) for k in range(nl)]
+        gn = rs.randn(B, L * (2 * r + 1) ** 2, H, W).astype(np.float32)
+        grads = []
+        for _ in range(2):
+            f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+            cb = CorrBlock(f1, f2, num_levels=L, radius=r)
+            torch.autograd.backward([cb(_t(c, dev)) for c in cons], [_t(gn, dev)] * nl)
+            grads.append((f1.grad.cpu().numpy(), f2.grad.cpu().numpy()))
+        assert np.array_equal(grads[0][0], grads[1][0]) and np.array_equal(grads[0][1], grads[1][1])
+        if W % 4:                                               # unaligned rows -> gemm_f32_kernel
+            c1, c2 = torch.from_numpy(f1n).requires_grad_(True), torch.from_numpy(f2n).requires_grad_(True)
+            ob = O.CorrBlockOracle(c1, c2, L, r)
+            torch.autograd.backward([ob(torch.from_numpy(c)) for c in cons], [torch.from_numpy(gn)] * nl)
+            assert rel_err(grads[0][0], c1.grad.numpy()) <= GTOL and rel_err(grads[0][1], c2.grad.numpy()) <= GTOL
+
+
 def test_on_the_fly_backward_is_bit_reproducible(dev):
     """raftcorr_alt_lookup_bwd has one writer per gradient element and a fixed summation order (no atomics):
     two runs on the same inputs must agree bit for bit, also with incoherent flow (long partner lists, split
