@@ -100,6 +100,25 @@ int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2,
                                 float* const* levels, void* workspace, int64_t workspace_bytes,
                                 int precision, void* stream);
 
+/* 16-bit volume (no reference line: the reference's volume is always float32; north star "bf16" option, SURVEY 8
+ * shape table "4.26 GB (bf16 2.13)").  raftcorr_build_pyramid_vol = raftcorr_build_pyramid_prec with the pyramid
+ * stored as fp16 or bf16 ELEMENTS in the same slab / patch-tile element order (levels[l] then points at
+ * B*H*W*slab[l] 16-bit elements): every value is rounded once from the fp32 accumulator, pooled levels from
+ * their fp32 sums.  Halves the build's store traffic and the lookup's line traffic; results differ from the
+ * float32 volume by the element rounding (bf16: 2^-9 relative, the <= 1e-2 class; fp16: 2^-12, values beyond
+ * +-65504 become inf).  num_levels <= 4.  raftcorr_lookup_fwd_vol reads such a pyramid (volume_dtype must be
+ * the one it was built with); output float32 as raftcorr_lookup_fwd.  The backward entry points never read the
+ * volume values (raftcorr_lookup_bwd with dcoords == NULL, raftcorr_build_bwd) and serve either kind. */
+#define RAFTCORR_VOL_FP32 0
+#define RAFTCORR_VOL_FP16 1
+#define RAFTCORR_VOL_BF16 2
+int raftcorr_build_pyramid_vol(const float* fmap1, const float* fmap2,
+                               int B, int D, int H, int W, int num_levels,
+                               void* const* levels, void* workspace, int64_t workspace_bytes,
+                               int precision, int volume_dtype, void* stream);
+int raftcorr_lookup_fwd_vol(const void* const* levels, int volume_dtype, int B, int H, int W, int num_levels,
+                            int radius, const float* coords, int mode, float* out, void* stream);
+
 /* Allocation-free variant of raftcorr_build_pyramid_prec.  NO COUNTERPART IN THE REFERENCE: it exists
  * for callers that cannot allocate device memory -- code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc -- and therefore cannot bring the workspace the other build

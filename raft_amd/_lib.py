@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libraftcorr.so")
 
 MAX_LEVELS = 8
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 3}          # RAFTCORR_PREC_*
+VOLUMES = {"fp32": 0, "fp16": 1, "bf16": 2}                              # RAFTCORR_VOL_*
 MODE_FORK = 0
 MODE_CANONICAL = 1
 
@@ -41,6 +42,10 @@ _SIGNATURES = {
                                      _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, ctypes.c_void_p], _c_int),
     "raftcorr_lookup_fwd": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_build_pyramid_vol": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_void_p),
+                                    _c_fp, ctypes.c_int64, _c_int, _c_int, ctypes.c_void_p], _c_int),
+    "raftcorr_lookup_fwd_vol": ([ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 _c_fp, _c_int, _c_fp, ctypes.c_void_p], _c_int),
     "raftcorr_lookup_bwd": ([ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                              _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp,
                              ctypes.c_void_p], _c_int),

@@ -85,8 +85,11 @@ class _Pyramid:
     """Packed pyramid storage (patch-tile order, include/raftcorr.h) + the shared gradient
     accumulator of one CorrBlock."""
 
-    def __init__(self, B, H, W, num_levels, device):
+    def __init__(self, B, H, W, num_levels, device, volume="fp32"):
         self.B, self.H, self.W, self.L = B, H, W, num_levels
+        self.volume = volume                                    # element type of the stored volume
+        self.vol = _lib.VOLUMES[volume]
+        self.vdtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[volume]
         self.N = H * W
         self.layout = _lib.level_layout(H, W, num_levels)       # [(H_l, W_l, slab_l)]
         self.offsets = []
@@ -132,7 +135,7 @@ class _Pyramid:
         for l, ((h, w, _), s) in enumerate(zip(self.layout, self.slabs(flat))):
             if l not in self._index:
                 self._index[l] = torch.from_numpy(_lib.level_positions(self.H, self.W, l)).to(self.device)
-            out.append(s.index_select(1, self._index[l]).view(self.B * self.N, 1, h, w))
+            out.append(s.index_select(1, self._index[l]).view(self.B * self.N, 1, h, w).float())
         return out
 
     def attach(self, flat):
@@ -170,14 +173,14 @@ def _build(fmap1, fmap2, pyr, precision="fp32"):
     lib = _lib.load()
 
     B, D, H, W = fmap1.shape
-    flat = torch.empty(pyr.total, dtype=torch.float32, device=fmap1.device)
+    flat = torch.empty(pyr.total, dtype=pyr.vdtype, device=fmap1.device)
     pyr.attach(flat)
     wbytes = lib.raftcorr_build_workspace_bytes(B, D, H, W)
     work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
     with _guard(fmap1):
-        _lib.check(lib.raftcorr_build_pyramid_prec(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
-                                                   pyr.ptrs, work.data_ptr(), wbytes,
-                                                   _lib.PRECISIONS[precision], _stream(fmap1)), "build_pyramid")
+        _lib.check(lib.raftcorr_build_pyramid_vol(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L,
+                                                  pyr.ptrs, work.data_ptr(), wbytes,
+                                                  _lib.PRECISIONS[precision], pyr.vol, _stream(fmap1)), "build_pyramid")
     return flat
 
 
@@ -225,7 +228,14 @@ def _lookup(pyr, coords, radius, mode):
     # the argtypes-free ctypes handle with prebuilt arguments (_lib.fast) -- host cost only, same kernels
     out = coords.new_empty(pyr.out_shape(radius, mode))      # coords is float32 on the volume's device (checked by the caller)
     with _guard(coords):
-        if _pyfast is not None:
+        if pyr.vol:                                              # 16-bit volume: same call with the element type
+            if _pyfast is not None:
+                rc = _pyfast.lookup_fwd_vol(_lib.fn_addr("raftcorr_lookup_fwd_vol"), pyr.ptrs_addr, pyr.vol, pyr.B, pyr.H,
+                                            pyr.W, pyr.L, radius, coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
+            else:
+                rc = _lib.load().raftcorr_lookup_fwd_vol(pyr.ptrs, pyr.vol, pyr.B, pyr.H, pyr.W, pyr.L, radius,
+                                                         coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
+        elif _pyfast is not None:
             rc = _pyfast.lookup_fwd(_lib.fn_addr("raftcorr_lookup_fwd"), pyr.ptrs_addr, pyr.B, pyr.H, pyr.W,
                                     pyr.L, radius, coords.data_ptr(), mode, out.data_ptr(), _stream(coords))
         else:
@@ -254,6 +264,9 @@ class _Lookup(torch.autograd.Function):
         dout = _f32c(dout)
         need_vol = ctx.needs_input_grad[0]
         need_co = ctx.needs_input_grad[1]
+        if need_co and pyr.vol:
+            raise RuntimeError("CorrBlock: the gradient w.r.t. coords needs a float32 volume (volume_dtype='fp32'); "
+                               "detach coords as core/raft.py:124 does")
         dcoords = torch.empty_like(coords) if need_co else None
         with _guard(coords):
             dptrs = None
@@ -282,14 +295,26 @@ class CorrBlock:
                 results (inside the 1e-5 parity bar by orders of magnitude), faster build;
       "fp16x2"  maps scaled by a power of two, operands split into two fp16 pieces, three fp16
                 MFMA products: fp32-grade too, the fastest of the accurate builds;
-      "bf16"    operands rounded to bfloat16: differs by the input rounding, <= 1e-2."""
+      "bf16"    operands rounded to bfloat16: differs by the input rounding, <= 1e-2.
 
-    def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32"):
+    volume_dtype (keyword, not in the reference): element type the pyramid is STORED in.  "fp32" (default) is
+    the reference's; "bf16" / "fp16" store every level in 16 bits (rounded once from the fp32 accumulators):
+    half the memory (1080p: 2.8 instead of 5.7 GB), half the build's store traffic and half the line traffic
+    of every lookup, at the price of the element rounding (bf16 2^-9, fp16 2^-12 relative; fp16 overflows
+    beyond +-65504) -- the <= 1e-2 class of the north star's bf16 option.  Lookups return float32 either way;
+    gradients w.r.t. the features work as usual, the gradient w.r.t. coords needs "fp32"."""
+
+    def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32", volume_dtype="fp32"):
         self.num_levels = num_levels
         self.radius = radius
         if precision not in _lib.PRECISIONS:
             raise RuntimeError(f"CorrBlock: precision must be one of {sorted(_lib.PRECISIONS)}; got {precision!r}")
+        if volume_dtype not in _lib.VOLUMES:
+            raise RuntimeError(f"CorrBlock: volume_dtype must be one of {sorted(_lib.VOLUMES)}; got {volume_dtype!r}")
+        if volume_dtype != "fp32" and num_levels > 4:
+            raise RuntimeError("CorrBlock: a 16-bit volume has at most 4 levels")
         self.precision = precision
+        self.volume_dtype = volume_dtype
         _require_cuda(fmap1=fmap1, fmap2=fmap2)
         if fmap1.dim() != 4 or fmap1.shape != fmap2.shape:
             raise RuntimeError(f"CorrBlock: fmap1/fmap2 must both be (B, D, H, W); got "
@@ -303,7 +328,7 @@ class CorrBlock:
         if (H >> (num_levels - 1)) < 1 or (W >> (num_levels - 1)) < 1:
             # the reference fails in F.avg_pool2d ("Output size is too small"), core/corr.py:26
             raise RuntimeError(f"CorrBlock: a {H} x {W} map has no level {num_levels - 1}: output size is too small")
-        self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device)
+        self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device, volume_dtype)
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
             flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr, precision)
             self._pyr.flat = flat.detach()
@@ -364,6 +389,8 @@ class CorrBlock:
             weight = weight[:, :, 0, 0]
         if weight.dim() != 2 or weight.shape[1] != cin:
             raise RuntimeError(f"CorrBlock: weight must be (Cout, {cin}[, 1, 1]); got {tuple(weight.shape)}")
+        if p.vol:
+            raise RuntimeError("CorrBlock.lookup_conv1x1 needs a float32 volume (volume_dtype='fp32')")
         if self.num_levels > 4 or self.radius not in (3, 4):
             raise RuntimeError("CorrBlock.lookup_conv1x1 supports num_levels <= 4 and radius 3 or 4")
         cout = weight.shape[0]

@@ -98,8 +98,9 @@ int64_t raftcorr_build_bwd_workspace_bytes(int B, int D, int H, int W)
 
 static int build_pyramid_any(const char* who, const float* fmap1, const float* fmap2, int B, int D, int H, int W,
                              int num_levels, float* const* levels, void* workspace, int64_t workspace_bytes,
-                             int precision, void* stream)
+                             int precision, void* stream, int vol = RAFTCORR_VOL_FP32)
 {
+    if (vol < RAFTCORR_VOL_FP32 || vol > RAFTCORR_VOL_BF16) return fail(RAFTCORR_EINVAL, "%s: volume_dtype = %d", who, vol);
     int rc = check_dims(who, B, H, W);
     if (rc) return rc;
     if (!fmap1 || !fmap2) return fail(RAFTCORR_EINVAL, "%s: null feature map", who);
@@ -110,7 +111,7 @@ static int build_pyramid_any(const char* who, const float* fmap1, const float* f
     rc = make_levels(who, levels, H, W, num_levels, lv);
     if (rc) return rc;
     return launch_build_pyramid(fmap1, fmap2, B, D, H, W, num_levels, lv, workspace,
-                                workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, precision, (hipStream_t)stream);
+                                workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, precision, (hipStream_t)stream, vol);
 }
 
 int raftcorr_build_pyramid(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
@@ -127,6 +128,33 @@ int raftcorr_build_pyramid_prec(const float* fmap1, const float* fmap2, int B, i
 {
     return build_pyramid_any("build_pyramid_prec", fmap1, fmap2, B, D, H, W, num_levels, levels, workspace,
                              workspace_bytes, precision, stream);
+}
+
+int raftcorr_build_pyramid_vol(const float* fmap1, const float* fmap2, int B, int D, int H, int W,
+                               int num_levels, void* const* levels, void* workspace, int64_t workspace_bytes,
+                               int precision, int volume_dtype, void* stream)
+{
+    return build_pyramid_any("build_pyramid_vol", fmap1, fmap2, B, D, H, W, num_levels, (float* const*)levels, workspace,
+                             workspace_bytes, precision, stream, volume_dtype);
+}
+
+int raftcorr_lookup_fwd_vol(const void* const* levels, int volume_dtype, int B, int H, int W, int num_levels, int radius,
+                            const float* coords, int mode, float* out, void* stream)
+{
+    int rc = check_dims("lookup_fwd_vol", B, H, W);
+    if (rc) return rc;
+    if (!coords || !out) return fail(RAFTCORR_EINVAL, "lookup_fwd_vol: null coords/out");
+    if (radius < 0) return fail(RAFTCORR_EINVAL, "lookup_fwd_vol: radius = %d", radius);
+    if (mode != RAFTCORR_MODE_FORK && mode != RAFTCORR_MODE_CANONICAL)
+        return fail(RAFTCORR_EINVAL, "lookup_fwd_vol: mode = %d", mode);
+    if (volume_dtype < RAFTCORR_VOL_FP32 || volume_dtype > RAFTCORR_VOL_BF16)
+        return fail(RAFTCORR_EINVAL, "lookup_fwd_vol: volume_dtype = %d", volume_dtype);
+    if (volume_dtype != RAFTCORR_VOL_FP32 && num_levels > 4)
+        return fail(RAFTCORR_EUNSUPPORTED, "lookup_fwd_vol: a 16-bit volume has at most 4 levels (got %d)", num_levels);
+    LevelSet lv;
+    rc = make_levels("lookup_fwd_vol", (const float* const*)levels, H, W, num_levels, lv);
+    if (rc) return rc;
+    return launch_lookup_fwd(lv, B, H, W, num_levels, radius, coords, mode, out, (hipStream_t)stream, volume_dtype);
 }
 
 int raftcorr_build_pyramid_noalloc(const float* fmap1, const float* fmap2, int B, int D, int H, int W,

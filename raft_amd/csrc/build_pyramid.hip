@@ -190,9 +190,33 @@ __device__ __forceinline__ void block_to_tile(const BuildArgs& p, int& b, int& t
 #define RC_EPI_AUX 0        // cache-policy bits of the epilogue's buffer stores (lab knob)
 #endif
 
+// 16-bit volume element (RAFTCORR_VOL_*): fp16 = RNE, beyond +-65504 -> inf; bf16 = RNE
+template <int VOL>
+__device__ __forceinline__ unsigned vol16(float x)
+{
+    if (VOL == 1) return __builtin_bit_cast(unsigned short, (_Float16)x);
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+
+// one pooled cell -> its level, as float32 or as a 16-bit element
+template <int VOL>
+__device__ __forceinline__ void store_cell(float v, __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    if (VOL == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, RC_EPI_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)vol16<VOL>(v), r, off, 0, RC_EPI_AUX);
+}
+
 // Shared by the fp32 and bf16 kernels (both MFMAs have the same 32x32 C/D map): scale, store
-// level 0, pool levels 1..3 out of the accumulators.
-template <bool EXACT_MUL>
+// level 0, pool levels 1..3 out of the accumulators.  VOL: element type of the pyramid (0 = float32;
+// 1 = fp16, 2 = bf16: same element order, every value rounded once from the fp32 accumulators, the
+// pooled levels from their fp32 sums -- half the store traffic of the build and half the line
+// traffic of every lookup).
+template <bool EXACT_MUL, int VOL>
 __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)[4], int b, int tn, int m0,
                                                int wave, int lane)
 {
@@ -213,28 +237,27 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
     const int rows = min(32, p.N - q0w);
     if (rows <= 0) return;                                   // wave-uniform
     const int L = p.L;
+    constexpr unsigned ES = VOL ? 2 : 4;                     // bytes per volume element
     __amdgpu_buffer_rsrc_t r0, r1, r2, r3;
     {
         const size_t qb = (size_t)b * p.N + q0w;
-        r0 = __builtin_amdgcn_make_buffer_rsrc(p.lvl[0] + qb * p.slab[0], 0, (int)(rows * p.slab[0] * 4), 0x00020000);
-        r1 = __builtin_amdgcn_make_buffer_rsrc(L > 1 ? p.lvl[1] + qb * p.slab[1] : p.lvl[0], 0,
-                                               L > 1 ? (int)(rows * p.slab[1] * 4) : 0, 0x00020000);
-        r2 = __builtin_amdgcn_make_buffer_rsrc(L > 2 ? p.lvl[2] + qb * p.slab[2] : p.lvl[0], 0,
-                                               L > 2 ? (int)(rows * p.slab[2] * 4) : 0, 0x00020000);
-        r3 = __builtin_amdgcn_make_buffer_rsrc(L > 3 ? p.lvl[3] + qb * p.slab[3] : p.lvl[0], 0,
-                                               L > 3 ? (int)(rows * p.slab[3] * 4) : 0, 0x00020000);
+        auto base = [&](int l) { return (char*)p.lvl[l] + qb * p.slab[l] * ES; };      // levels are byte-addressed here
+        r0 = __builtin_amdgcn_make_buffer_rsrc(base(0), 0, (int)(rows * p.slab[0] * ES), 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc(L > 1 ? base(1) : base(0), 0, L > 1 ? (int)(rows * p.slab[1] * ES) : 0, 0x00020000);
+        r2 = __builtin_amdgcn_make_buffer_rsrc(L > 2 ? base(2) : base(0), 0, L > 2 ? (int)(rows * p.slab[2] * ES) : 0, 0x00020000);
+        r3 = __builtin_amdgcn_make_buffer_rsrc(L > 3 ? base(3) : base(0), 0, L > 3 ? (int)(rows * p.slab[3] * ES) : 0, 0x00020000);
     }
-    const unsigned s0b = (unsigned)(p.slab[0] * 4), s1b = (unsigned)(p.slab[1] * 4);
-    const unsigned s2b = (unsigned)(p.slab[2] * 4), s3b = (unsigned)(p.slab[3] * 4);
+    const unsigned s0b = (unsigned)(p.slab[0] * ES), s1b = (unsigned)(p.slab[1] * ES);
+    const unsigned s2b = (unsigned)(p.slab[2] * ES), s3b = (unsigned)(p.slab[3] * ES);
     // Lane l31 holds cells 4*l31 .. 4*l31+3 of the patch (accumulator n = cell 4*l31 + n): one
     // even-aligned 2x2 block of level 0.  Bits of l31 (layout.h): a0 = dy1, a1 = dx1, a2 = dx2,
     // a3 = column half, a4 = row half of the patch.
     const int a0 = lane & 1, a1 = (lane >> 1) & 1, a2 = (lane >> 2) & 1, a3 = (lane >> 3) & 1, a4 = (lane >> 4) & 1;
-    const unsigned c0 = (unsigned)(tn * 128 + 4 * l31) * 4;
-    const unsigned c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * 4;
-    const unsigned c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * 4;
+    const unsigned c0 = (unsigned)(tn * 128 + 4 * l31) * ES;
+    const unsigned c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * ES;
+    const unsigned c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * ES;
     const int ph = tn / p.PW, pwi = tn - ph * p.PW;
-    const unsigned c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * 4;
+    const unsigned c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * ES;
     const int quad = lane & 3;
     const unsigned rowk = 4 * kh;
 
@@ -248,12 +271,18 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
             v[n] = EXACT_MUL ? acc[n][reg] * (p.inv_sqrt_d * unscale) : (acc[n][reg] * unscale) / p.sqrt_d;
-        u32x4s w;
-        w.x = __float_as_uint(v[0]); w.y = __float_as_uint(v[1]); w.z = __float_as_uint(v[2]); w.w = __float_as_uint(v[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(w, r0, row * s0b + c0, 0, RC_EPI_AUX);    // 32 lanes = 512 contiguous bytes
+        if (VOL == 0) {
+            u32x4s w;
+            w.x = __float_as_uint(v[0]); w.y = __float_as_uint(v[1]); w.z = __float_as_uint(v[2]); w.w = __float_as_uint(v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(w, r0, row * s0b + c0, 0, RC_EPI_AUX);    // 32 lanes = 512 contiguous bytes
+        } else {
+            u32x2s w;
+            w.x = vol16<VOL>(v[0]) | (vol16<VOL>(v[1]) << 16); w.y = vol16<VOL>(v[2]) | (vol16<VOL>(v[3]) << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(w, r0, row * s0b + c0, 0, RC_EPI_AUX);     // 32 lanes = 256 contiguous bytes
+        }
         if (L > 1) {
             const float t1 = (v[0] + v[1]) + (v[2] + v[3]);                   // the lane's own 2x2 block
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t1 * 0.25f), r1, row * s1b + c1, 0, RC_EPI_AUX);
+            store_cell<VOL>(t1 * 0.25f, r1, row * s1b + c1);
             if (L > 2) {
                 const float s = t1 + dpp<DPP_XOR1>(t1);
                 t2[reg] = s + dpp<DPP_XOR2>(s);                               // 4x4 sum, in all 4 lanes of the quad
@@ -271,8 +300,7 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
         for (int i = 0; i < 4; ++i) {                                          // registers 4i .. 4i+3 = rows 8i + 4kh + 0..3
             const float lo = (quad & 1) ? t2[4 * i + 1] : t2[4 * i], hi = (quad & 1) ? t2[4 * i + 3] : t2[4 * i + 2];
             const float mine = (quad & 2) ? hi : lo;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine * 0.0625f), r2,
-                                                  (unsigned)(8 * i + quad + rowk) * s2b + c2, 0, RC_EPI_AUX);
+            store_cell<VOL>(mine * 0.0625f, r2, (unsigned)(8 * i + quad + rowk) * s2b + c2);
         }
         if (L > 3) {
             const int rho = (lane & 7) | (a4 << 3);                            // this lane's register among the 16
@@ -284,13 +312,12 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
 #undef RC_SEL8
 #undef RC_SEL4
 #undef RC_SEL2
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine * 0.015625f), r3,
-                                                  (unsigned)((rho & 3) + 8 * (rho >> 2) + rowk) * s3b + c3, 0, RC_EPI_AUX);
+            store_cell<VOL>(mine * 0.015625f, r3, (unsigned)((rho & 3) + 8 * (rho >> 2) + rowk) * s3b + c3);
         }
     }
 }
 
-template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD>
+template <bool EXACT_MUL, int BK, int WAVES_PER_SIMD, int VOL = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD)
 void corr_build_f32_kernel(BuildArgs p)
 {
@@ -377,7 +404,7 @@ void corr_build_f32_kernel(BuildArgs p)
         for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
     return;
 #endif
-    build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
+    build_epilogue<EXACT_MUL, VOL>(p, acc, b, tn, m0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -518,7 +545,7 @@ void corr_pack_bf16_kernel(PackArgs p)
 #define RC_BF16_WAVES 3     // waves per SIMD the 16-bit kernels' registers are bounded for (lab knob)
 #endif
 
-template <bool EXACT_MUL, int NP, bool F16>
+template <bool EXACT_MUL, int NP, bool F16, int VOL = 0>
 __global__ __launch_bounds__(256, RC_BF16_WAVES)
 void corr_build_bf16_kernel(BuildArgs p)
 {
@@ -624,7 +651,7 @@ void corr_build_bf16_kernel(BuildArgs p)
         for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[n][i]));
     return;
 #endif
-    build_epilogue<EXACT_MUL>(p, acc, b, tn, m0, wave, lane);
+    build_epilogue<EXACT_MUL, VOL>(p, acc, b, tn, m0, wave, lane);
 }
 
 // levels >= 4: 2x2 mean of the previous level (rare: RAFT uses 4 levels); output row-major
@@ -655,8 +682,10 @@ size_t build_workspace_bytes(int B, int D, int H, int W)
 }
 
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s)
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s, int vol)
 {
+    if (vol != RAFTCORR_VOL_FP32 && L > 4)
+        return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: a 16-bit volume has at most 4 levels (got %d)", L);
     const bool bf16 = precision != RAFTCORR_PREC_FP32;          // 16-bit pieces on the bf16/fp16 matrix cores
     const bool f16 = precision == RAFTCORR_PREC_FP16X2;
     const int np = precision == RAFTCORR_PREC_BF16X3 ? 3 : f16 ? 2 : 1;
@@ -672,7 +701,7 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     // bf16 on volumes far beyond the 256 MB infinity cache is bound by HBM write efficiency: one
     // query tile at a time per XCD keeps each row's concurrently written segment long (measured at
     // 1080p: 1.61 ms vs 2.35 ms with groups of 8; at Sintel size the grouping of 8 is the faster one)
-    a.group_m = (bf16 && (double)B * a.N * (double)lv.g[0].slab * 4.0 > 1.0e9) ? 1 : GROUP_M;
+    a.group_m = (bf16 && (double)B * a.N * (double)lv.g[0].slab * (vol ? 2.0 : 4.0) > 1.0e9) ? 1 : GROUP_M;
 #if defined(RC_LAB)                    // tools/ only (tools/Makefile passes -DRC_LAB): never in libraftcorr.so
     if (const char* e = getenv("RC_GROUP_M")) a.group_m = atoi(e) > 0 ? atoi(e) : GROUP_M;
 #endif
@@ -713,21 +742,28 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     const long long nblk = (long long)a.nblk_per_b * B;
     if (nblk > 0x7fffffffLL) return fail(RAFTCORR_EUNSUPPORTED, "build_pyramid: grid too large");
     dim3 grid((unsigned)nblk), block(256);
+#define RC_LAUNCH_VOL(KERNEL, ...)                                                                           \
+    do {                                                                                                     \
+        if (vol == RAFTCORR_VOL_FP16)      hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 1>), grid, block, 0, s, a); \
+        else if (vol == RAFTCORR_VOL_BF16) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 2>), grid, block, 0, s, a); \
+        else                               hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 0>), grid, block, 0, s, a); \
+    } while (0)
     if (bf16) {
         if (f16) {
-            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 2, true>), grid, block, 0, s, a);
-            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 2, true>), grid, block, 0, s, a);
+            if (exact) RC_LAUNCH_VOL(corr_build_bf16_kernel, true, 2, true);
+            else       RC_LAUNCH_VOL(corr_build_bf16_kernel, false, 2, true);
         } else if (np == 3) {
-            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 3, false>), grid, block, 0, s, a);
-            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 3, false>), grid, block, 0, s, a);
+            if (exact) RC_LAUNCH_VOL(corr_build_bf16_kernel, true, 3, false);
+            else       RC_LAUNCH_VOL(corr_build_bf16_kernel, false, 3, false);
         } else {
-            if (exact) hipLaunchKernelGGL((corr_build_bf16_kernel<true, 1, false>), grid, block, 0, s, a);
-            else       hipLaunchKernelGGL((corr_build_bf16_kernel<false, 1, false>), grid, block, 0, s, a);
+            if (exact) RC_LAUNCH_VOL(corr_build_bf16_kernel, true, 1, false);
+            else       RC_LAUNCH_VOL(corr_build_bf16_kernel, false, 1, false);
         }
     } else {
-        if (exact) hipLaunchKernelGGL((corr_build_f32_kernel<true, BK, WPS>), grid, block, 0, s, a);
-        else       hipLaunchKernelGGL((corr_build_f32_kernel<false, BK, WPS>), grid, block, 0, s, a);
+        if (exact) RC_LAUNCH_VOL(corr_build_f32_kernel, true, BK, WPS);
+        else       RC_LAUNCH_VOL(corr_build_f32_kernel, false, BK, WPS);
     }
+#undef RC_LAUNCH_VOL
     rc = check_launch(bf16 ? "corr_build_bf16_kernel" : "corr_build_f32_kernel");
     if (rc) return rc;
     for (int l = 4; l < L; ++l) {
@@ -795,7 +831,7 @@ int launch_build_pyramid_noalloc(const float* f1, const float* f2, int B, int D,
     void* ptr = nullptr;
     const int rc = noalloc_scratch(&ptr);
     if (rc) return rc;
-    return launch_build_pyramid(f1, f2, B, D, H, W, L, lv, ptr, NOALLOC_SCRATCH_BYTES, precision, s);
+    return launch_build_pyramid(f1, f2, B, D, H, W, L, lv, ptr, NOALLOC_SCRATCH_BYTES, precision, s, RAFTCORR_VOL_FP32);
 }
 
 }  // namespace raftcorr

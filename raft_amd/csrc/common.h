@@ -20,11 +20,12 @@ struct LevelSet {                 // by-value kernel argument: per-level pointer
 size_t build_workspace_bytes(int B, int D, int H, int W);
 size_t build_bwd_workspace_bytes(int B, int D, int H, int W);
 int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                         const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s);
+                         const LevelSet& lv, void* workspace, size_t workspace_bytes, int precision, hipStream_t s,
+                         int vol = RAFTCORR_VOL_FP32);
 int launch_build_pyramid_noalloc(const float* f1, const float* f2, int B, int D, int H, int W, int L,
                                  const LevelSet& lv, int precision, hipStream_t s);
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
-                      int mode, float* out, hipStream_t s);
+                      int mode, float* out, hipStream_t s, int vol = RAFTCORR_VOL_FP32);
 int launch_lookup_bwd(const LevelSet& lv, const LevelSet& dlv, bool have_dlevels, int B, int H, int W,
                       int L, int r, const float* coords, int mode, const float* dout,
                       float* dcoords, hipStream_t s);

@@ -266,10 +266,38 @@ __device__ __forceinline__ unsigned short bf16_rne(float x)
     return (unsigned short)(u >> 16);
 }
 
+// Volume element access by type (RAFTCORR_VOL_*: 0 float32, 1 fp16, 2 bf16).  `vol` is the level's base as a byte
+// pointer's worth of float* (api.hip hands 16-bit levels through the same LevelSet); offsets are in ELEMENTS.
+template <int VOL>
+__device__ __forceinline__ float vol_elem(unsigned short h)
+{
+    if (VOL == 1) return (float)__builtin_bit_cast(_Float16, h);
+    return __uint_as_float((unsigned)h << 16);
+}
+template <int VOL>
+__device__ __forceinline__ const float* vol_base(const float* level, size_t elems)
+{
+    return VOL == 0 ? level + elems : (const float*)((const unsigned short*)level + elems);
+}
+template <int VOL>
+__device__ __forceinline__ float vol_load1(const float* vol, int o)
+{
+    if (VOL == 0) return vol[o];
+    return vol_elem<VOL>(((const unsigned short*)vol)[o]);
+}
+template <int VOL>
+__device__ __forceinline__ float4 vol_load_block(const float* vol, int o)        // one even-aligned 2x2 block
+{
+    if (VOL == 0) return *(const float4*)(vol + o);
+    const uint2 w = *(const uint2*)((const unsigned short*)vol + o);             // 8 bytes
+    return make_float4(vol_elem<VOL>((unsigned short)w.x), vol_elem<VOL>((unsigned short)(w.x >> 16)),
+                       vol_elem<VOL>((unsigned short)w.y), vol_elem<VOL>((unsigned short)(w.y >> 16)));
+}
+
 // NT: threads that work on the block's 32 queries.  The stand-alone kernel runs QB * RD of them (R = 4: 288):
 // one thread per (query, window column) in the blend, and the block loads (QB * NB^2), the table entries and
 // the per-sample entries all divide evenly over them.  The fused kernel gives each level a 256-thread group.
-template <int R, int KIND, int NT>
+template <int R, int KIND, int NT, int VOL = 0>
 __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* smem, int l, int b, int q0, int tid,
                                                   float* xsink = nullptr)
 {
@@ -287,7 +315,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
 
     const LevelGeom g = p.lv.g[l];
     const int N = p.N;
-    const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
+    const float* __restrict__ vol = vol_base<VOL>(p.lv.ptr[l], ((size_t)b * N + q0) * g.slab);   // block's first slab
 
     RC_STAMP(0);
     // phase 0: block-offset tables + masks (2 QB NB entries).  The per-sample taps / fractions / row weights
@@ -384,7 +412,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
             const int by = blk / NB, bx = blk - by * NB;
             const int o = bytab[qi * NB + by] + bxtab[qi * NB + bx];
             off[i] = (e < QB * NBLK && o >= 0) ? o : -1;
-            v[i] = *(const float4*)(vol + max(o, 0));     // absent blocks read a valid dummy address
+            v[i] = vol_load_block<VOL>(vol, max(o, 0));   // absent blocks read a valid dummy address
             xmk[i] = xmask[qi]; ymk[i] = ymask[qi];       // read now: no LDS round trip once the taps have landed
         }
         __builtin_amdgcn_sched_barrier(0);                // the loads are in flight: now the sample tables
@@ -486,7 +514,7 @@ __device__ __forceinline__ void lookup_fwd_blocks(const LookupArgs& p, float* sm
     RC_STAMP(3);
 }
 
-template <int R, int KIND, int NT>
+template <int R, int KIND, int NT, int VOL = 0>
 __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem)
 {
     const int r = (R >= 0) ? R : p.r;
@@ -504,7 +532,7 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
     const int tid = threadIdx.x;
     const LevelGeom g = p.lv.g[l];
     const int N = p.N;
-    const float* __restrict__ vol = p.lv.ptr[l] + ((size_t)b * N + q0) * g.slab;   // block's first slab
+    const float* __restrict__ vol = vol_base<VOL>(p.lv.ptr[l], ((size_t)b * N + q0) * g.slab);   // block's first slab
 
     RC_STAMP(0);
     build_tables<R, KIND, NT>(p, s, g, b, q0, l, r);
@@ -542,7 +570,7 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
             const int ty = t / Tc, tx = t - ty * Tc;
             const int o = s.ytab[qc * Tc + ty] + s.xtab[qc * Tc + tx];
             off[i] = (qi < QB && o >= 0) ? o : -1;
-            v[i] = vol[max(o, 0)];                // invalid taps read a valid dummy address
+            v[i] = vol_load1<VOL>(vol, max(o, 0));   // invalid taps read a valid dummy address
             t += NT % TTc; qi += NT / TTc;
             if (t >= TTc) { t -= TTc; ++qi; }
         }
@@ -559,7 +587,7 @@ __device__ __forceinline__ void lookup_fwd_body(const LookupArgs& p, float* smem
             const int t = e - qi * TT;
             const int ty = t / T, tx = t - ty * T;
             const int o = s.ytab[qi * T + ty] + s.xtab[qi * T + tx];
-            taps[qi * ST + t] = o >= 0 ? vol[o] : 0.f;
+            taps[qi * ST + t] = o >= 0 ? vol_load1<VOL>(vol, o) : 0.f;
         }
     }
     __syncthreads();
@@ -603,7 +631,7 @@ struct FwdThreads { static constexpr int NT = 256; };
 struct FwdThreads { static constexpr int NT = R >= 0 ? QB * (2 * R + 1) : 256; };
 #endif
 
-template <int R>
+template <int R, int VOL = 0>
 __global__ __launch_bounds__(FwdThreads<R>::NT)
 void corr_lookup_fwd_kernel(LookupArgs p)
 {
@@ -615,19 +643,19 @@ void corr_lookup_fwd_kernel(LookupArgs p)
     const int kind = min((int)blockIdx.y, 4);    // block-uniform
     if constexpr (R >= 0) {
         switch (kind) {
-        case 0: lookup_fwd_blocks<R, 0, NT>(p, smem, 0, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 1: lookup_fwd_blocks<R, 1, NT>(p, smem, 1, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 2: lookup_fwd_blocks<R, 2, NT>(p, smem, 2, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        case 3: lookup_fwd_blocks<R, 3, NT>(p, smem, 3, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
-        default: lookup_fwd_body<R, 4, NT>(p, smem); return;
+        case 0: lookup_fwd_blocks<R, 0, NT, VOL>(p, smem, 0, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 1: lookup_fwd_blocks<R, 1, NT, VOL>(p, smem, 1, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 2: lookup_fwd_blocks<R, 2, NT, VOL>(p, smem, 2, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        case 3: lookup_fwd_blocks<R, 3, NT, VOL>(p, smem, 3, blockIdx.z, blockIdx.x * QB, threadIdx.x); return;
+        default: lookup_fwd_body<R, 4, NT, VOL>(p, smem); return;
         }
     } else {
         switch (kind) {
-        case 0: lookup_fwd_body<R, 0, NT>(p, smem); break;
-        case 1: lookup_fwd_body<R, 1, NT>(p, smem); break;
-        case 2: lookup_fwd_body<R, 2, NT>(p, smem); break;
-        case 3: lookup_fwd_body<R, 3, NT>(p, smem); break;
-        default: lookup_fwd_body<R, 4, NT>(p, smem); break;
+        case 0: lookup_fwd_body<R, 0, NT, VOL>(p, smem); break;
+        case 1: lookup_fwd_body<R, 1, NT, VOL>(p, smem); break;
+        case 2: lookup_fwd_body<R, 2, NT, VOL>(p, smem); break;
+        case 3: lookup_fwd_body<R, 3, NT, VOL>(p, smem); break;
+        default: lookup_fwd_body<R, 4, NT, VOL>(p, smem); break;
         }
     }
 }
@@ -1049,7 +1077,7 @@ static size_t lookup_smem(int r, bool bwd)
 }
 
 int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, const float* coords,
-                      int mode, float* out, hipStream_t s)
+                      int mode, float* out, hipStream_t s, int vol)
 {
     LookupArgs a = {};
     a.lv = lv; a.coords = coords; a.out = out;
@@ -1058,9 +1086,16 @@ int launch_lookup_fwd(const LevelSet& lv, int B, int H, int W, int L, int r, con
     const size_t sm = lookup_smem(r, false);
     if (sm > 64 * 1024) return fail(RAFTCORR_EUNSUPPORTED, "lookup_fwd: radius %d too large", r);
     dim3 grid((a.N + QB - 1) / QB, L, B);
-    if (r == 4)      hipLaunchKernelGGL(corr_lookup_fwd_kernel<4>, grid, dim3(FwdThreads<4>::NT), sm, s, a);
-    else if (r == 3) hipLaunchKernelGGL(corr_lookup_fwd_kernel<3>, grid, dim3(FwdThreads<3>::NT), sm, s, a);
-    else             hipLaunchKernelGGL(corr_lookup_fwd_kernel<-1>, grid, dim3(256), sm, s, a);
+#define RC_LAUNCH_FWD(VOL)                                                                                          \
+    do {                                                                                                            \
+        if (r == 4)      hipLaunchKernelGGL((corr_lookup_fwd_kernel<4, VOL>), grid, dim3(FwdThreads<4>::NT), sm, s, a); \
+        else if (r == 3) hipLaunchKernelGGL((corr_lookup_fwd_kernel<3, VOL>), grid, dim3(FwdThreads<3>::NT), sm, s, a); \
+        else             hipLaunchKernelGGL((corr_lookup_fwd_kernel<-1, VOL>), grid, dim3(256), sm, s, a);              \
+    } while (0)
+    if (vol == RAFTCORR_VOL_FP16)      RC_LAUNCH_FWD(1);
+    else if (vol == RAFTCORR_VOL_BF16) RC_LAUNCH_FWD(2);
+    else                               RC_LAUNCH_FWD(0);
+#undef RC_LAUNCH_FWD
     return check_launch("corr_lookup_fwd_kernel");
 }
 
