@@ -14,8 +14,8 @@ The other configs of BASELINE.json run through the same harness:
   things_train  configs[3]: FlyingThings crops 50x90, batch 6 per GPU, build + 12 lookups fwd + bwd;
                 with N > 1 ranks each step ends with the all-reduce of a RAFT-sized gradient bucket
                 (5,257,536 fp32, the DDP traffic of core/train.py's model) over RCCL
-  1080p         configs[4]: 136x240, bf16 MFMA all-pairs build + 32 lookups; the fp32 all-pairs and
-                the on-the-fly variants are timed beside it (extras)
+  1080p         configs[4]: 136x240, bf16 MFMA all-pairs build into a bf16 volume + 32 lookups; the float32-volume
+                all-pairs builds and the on-the-fly variant are timed beside it (extras)
 
 Multi-GPU: frame pairs are independent, so ranks run replicas with no data-path
 collective ("weak" scaling).  `--gpus N` with N > 1 started WITHOUT torchrun re-launches itself as
@@ -218,18 +218,18 @@ class SintelFwd(Workload):
 
 class Bf16AllPairs(SintelFwd):
     def kw(self):
-        return {"precision": "bf16"}
+        return {"precision": "bf16", "volume_dtype": "bf16"}
 
     def kernels(self, phases_us):
         w = work_of(self.cfg)
         iters = CONFIGS[self.cfg][4]
         build_us, lookup_us = phases_us[0], phases_us[1] / iters
-        kb = frac_entry("corr_build_bf16_kernel<1> (+ corr_pack_bf16_kernel)", build_us, "hbm", w["build_bytes"],
-                        HBM_PEAK_GBS, "GB/s", algorithmic_bytes=w["build_bytes"], algorithmic_flops=w["build_flops"],
+        kb = frac_entry("corr_build_bf16_kernel<1, bf16 volume> (+ corr_pack_bf16_kernel)", build_us, "hbm", w["build_bytes_16"],
+                        HBM_PEAK_GBS, "GB/s", algorithmic_bytes=w["build_bytes_16"], algorithmic_flops=w["build_flops"],
                         mfma_TFLOPs=w["build_flops"] / build_us / 1e6, traffic=None,
-                        note="bf16 operands, fp32 pyramid: bound by the pyramid's store traffic")
-        kl = frac_entry("corr_lookup_fwd_kernel", lookup_us, "hbm", w["lookup_bytes"], HBM_PEAK_GBS, "GB/s",
-                        algorithmic_bytes=w["lookup_bytes"], traffic=None)
+                        note="bf16 operands, bf16 pyramid: bound by the pyramid's store traffic")
+        kl = frac_entry("corr_lookup_fwd_kernel<4, bf16 volume>", lookup_us, "hbm", w["lookup_bytes_16"], HBM_PEAK_GBS, "GB/s",
+                        algorithmic_bytes=w["lookup_bytes_16"], traffic=None)
         return {"build": kb, "lookup": kl}, ("build" if build_us >= phases_us[1] else "lookup")
 
 
@@ -321,7 +321,7 @@ DEFAULT_STEPS = {"sintel": (200, 20), "kitti_alt": (50, 5), "things_train": (30,
 
 def lookup_fracs(torch, dev):
     """corr_lookup_fwd_kernel at the shapes where the launch latency is amortised:
-    Sintel B=1, Things B=6, 1080p; fp32 volume, canonical coordinates."""
+    Sintel B=1, Things B=6, 1080p; float32 and bf16 volume, canonical coordinates."""
     from raft_amd import CorrBlock
     out = {}
     g = torch.Generator().manual_seed(7)
@@ -332,12 +332,13 @@ def lookup_fracs(torch, dev):
         f2 = torch.randn(B, D, H, W, generator=g).to(dev)
         co = flow_coords(torch, B, H, W, 3, g)[2].to(dev)
         with torch.no_grad():
-            cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="fp16x2")
-            t = ev_time_us(torch, lambda: cb(co), reps=50, warm=5)
-            out[cfg + "_fp32"] = frac_entry("corr_lookup_fwd_kernel", t, "hbm", w["lookup_bytes"], HBM_PEAK_GBS,
-                                            "GB/s", algorithmic_bytes=w["lookup_bytes"],
-                                            shape=f"B={B} {H}x{W}")
-            del cb
+            for vol in ("fp32", "bf16"):
+                cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="fp16x2", volume_dtype=vol)
+                t = ev_time_us(torch, lambda: cb(co), reps=50, warm=5)
+                nbytes = w["lookup_bytes"] if vol == "fp32" else w["lookup_bytes_16"]
+                out[cfg + "_" + vol] = frac_entry("corr_lookup_fwd_kernel", t, "hbm", nbytes, HBM_PEAK_GBS, "GB/s",
+                                                  algorithmic_bytes=nbytes, shape=f"B={B} {H}x{W}", volume=vol)
+                del cb
         del f1, f2
         torch.cuda.empty_cache()
     return out
@@ -361,6 +362,21 @@ def extras_sintel(torch, wl, dev):
                 w["build_bytes"], HBM_PEAK_GBS, "GB/s", algorithmic_bytes=w["build_bytes"],
                 algorithmic_TFLOPs=w["build_flops"] / t / 1e6, executed_16bit_TFLOPs=terms * w["build_flops"] / t / 1e6,
                 note=note)
+        for prec, vol in (("bf16", "bf16"), ("fp16x2", "fp16")):
+            t = ev_time_us(torch, lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec, volume_dtype=vol),
+                           reps=100, warm=30)
+            out[f"build_{prec}_{vol}vol"] = frac_entry(
+                "corr_build_bf16_kernel, 16-bit volume (+ pack)", t, "hbm", w["build_bytes_16"], HBM_PEAK_GBS, "GB/s",
+                algorithmic_bytes=w["build_bytes_16"], algorithmic_TFLOPs=w["build_flops"] / t / 1e6,
+                note="pyramid stored in 16 bits: parity <= 1e-2 (bf16) / 1e-3 (fp16)")
+
+        def pair16():
+            cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="bf16", volume_dtype="bf16")
+            for c in coords:
+                cb(c)
+        t = ev_time_us(torch, pair16, reps=100, warm=10)
+        out["step_bf16_bf16vol"] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_step": t / 1e3, "steps": 100,
+                                    "note": f"bf16 operands, bf16 volume (parity <= 1e-2), then the same {iters} lookups"}
         alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
         for tag, c in (("alt_fwd_iter0", coords[0]), ("alt_fwd_iter8", coords[8])):
             t = ev_time_us(torch, lambda: alt(c))
@@ -475,17 +491,22 @@ def extras_1080p(torch, wl, dev):
     f1, f2, coords = wl.f1, wl.f2, wl.coords
     out = {}
     with torch.no_grad():
-        for prec in ("fp32", "fp16x2"):
+        for prec, vol in (("fp32", "fp32"), ("fp16x2", "fp32"), ("bf16", "fp32"), ("fp16x2", "fp16")):
             def pair():
-                cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec)
+                cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec, volume_dtype=vol)
                 for c in coords:
                     cb(c)
             t = ev_time_us(torch, pair, reps=5, warm=1)
-            tb = ev_time_us(torch, lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec), reps=5, warm=1)
-            out["all_pairs_" + prec] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_pair": t / 1e3, "build_us": tb,
-                                        "build_TFLOPs": w["build_flops"] / tb / 1e6,
-                                        "lookup_us": (t - tb) / iters,
-                                        "lookup_hbm_frac": w["lookup_bytes"] / ((t - tb) / iters) / 1e3 / HBM_PEAK_GBS}
+            tb = ev_time_us(torch, lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec, volume_dtype=vol),
+                            reps=5, warm=1)
+            lb = w["lookup_bytes"] if vol == "fp32" else w["lookup_bytes_16"]
+            bb = w["build_bytes"] if vol == "fp32" else w["build_bytes_16"]
+            out[f"all_pairs_{prec}_{vol}vol"] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_pair": t / 1e3, "build_us": tb,
+                                                 "build_TFLOPs": w["build_flops"] / tb / 1e6,
+                                                 "build_hbm_frac": bb / tb / 1e3 / HBM_PEAK_GBS,
+                                                 "lookup_us": (t - tb) / iters,
+                                                 "lookup_hbm_frac": lb / ((t - tb) / iters) / 1e3 / HBM_PEAK_GBS}
+            torch.cuda.empty_cache()
         alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
 
         def alt_pair():
@@ -717,7 +738,7 @@ def main():
             "kitti_alt": f"AlternateCorrBlock (on-the-fly), {iters} lookups fwd + bwd (r={RADIUS}, {LEVELS} levels)",
             "things_train": f"fp32 all-pairs build + {iters} lookups, fwd + bwd"
                             + (f" + all-reduce of {GRAD_BUCKET} fp32 (RCCL)" if world > 1 else ""),
-            "1080p": f"bf16-operand MFMA all-pairs build (fp32 pyramid) + {iters}-iter lookup fwd"}[args.config]
+            "1080p": f"bf16-operand MFMA all-pairs build (bf16 pyramid) + {iters}-iter lookup fwd"}[args.config]
     line["config"] = {"workload": f"{args.config}: {img_h}x{img_w} -> {H}x{W} (N={H * W}), batch {B}/GPU, D={D}, {what} "
                                   f"[BASELINE.json configs[{bidx}]]",
                       "parallelism": f"{ranks_seen} independent replica(s) (batch-sharded pairs"
