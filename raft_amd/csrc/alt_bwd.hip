@@ -55,7 +55,8 @@ struct AltBwdArgs {
     float* partial;                               // d(fmap2) partial tiles of the split levels
     long long poff[RAFTCORR_MAX_LEVELS];          // level l's offset in `partial` (floats)
     int nsplit[RAFTCORR_MAX_LEVELS];
-    int seg[RAFTCORR_MAX_LEVELS + 1];             // workgroups [0, seg[0]): d(fmap1); [seg[l], seg[l+1]): d(fmap2_l)
+    int seg[RAFTCORR_MAX_LEVELS + 1];             // workgroups [0, seg[0]): d(fmap1); [seg[l], seg[l+1]): d(fmap2_l);
+                                                  // every segment is padded to a multiple of 8 (one share per XCD)
     int B, C, Cp, H, W, L, r;
     int qtx, qtiles, ngroups;
     float sqrt_c;
@@ -357,9 +358,16 @@ void alt_bwd_kernel(AltBwdArgs p)
 #elif defined(RC_LAB_BWD_ONLY2)
     if (wg < p.seg[0]) return;
 #endif
+    // Workgroup id -> work item, XCD-aware: the hardware deals workgroups round-robin over the 8 XCDs, each with its
+    // own L2.  Inside a segment XCD x gets the x-th eighth of the item list, and the list is ordered so that an eighth
+    // is a band of image rows (tiles row-major; for the split levels the split index, i.e. a band of query tiles,
+    // comes first): the tiles a band shares -- partner images, d(out) tiles -- stay in that XCD's L2.
+    auto banded = [](int idx, int len) { return (idx & 7) * (len >> 3) + (idx >> 3); };
     if (wg < p.seg[0]) {
         // ---------------- d(fmap1): owner = query tile, partners = target tiles of every level ----------------
-        const int g = wg % p.ngroups, rest = wg / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
+        const int item = banded(wg, p.seg[0]);
+        if (item >= p.B * p.qtiles * p.ngroups) return;      // padding of the segment (whole workgroup)
+        const int g = item % p.ngroups, rest = item / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
         const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
         DTile dt;
         dtile_issue(p, dt, b, 0, tile, rd2, wave);
@@ -399,12 +407,15 @@ void alt_bwd_kernel(AltBwdArgs p)
     // ---------------- d(fmap2_l): owner = target tile, partners = query tiles whose windows touch it ----------------
     int l = 0;
     while (l + 1 < p.L && wg >= p.seg[l + 1]) ++l;
-    int idx = wg - p.seg[l];
-    const int g = idx % p.ngroups; idx /= p.ngroups;
     const int nsplit = p.nsplit[l];
-    const int s = idx % nsplit; idx /= nsplit;
     const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
-    const int tt = idx % ttiles, b = idx / ttiles;
+    int idx = banded(wg - p.seg[l], p.seg[l + 1] - p.seg[l]);
+    if (idx >= p.B * ttiles * nsplit * p.ngroups) return;    // padding of the segment (whole workgroup)
+    const int g = idx % p.ngroups; idx /= p.ngroups;
+    int s, tt;
+    if (ttiles >= 8 * nsplit) { s = idx % nsplit; idx /= nsplit; tt = idx % ttiles; idx /= ttiles; }    // bands of target tiles
+    else                      { tt = idx % ttiles; idx /= ttiles; s = idx % nsplit; idx /= nsplit; }    // bands of query tiles
+    const int b = idx;
     const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
     const int ty0 = (tt / ttx) * 8, tx0 = (tt % ttx) * 8;
     const int4* __restrict__ boxes = p.boxes + ((size_t)b * p.L + l) * p.qtiles;
@@ -525,7 +536,8 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
     pl.qtx = (W + QW - 1) / QW;
     pl.qtiles = pl.qtx * ((H + QH - 1) / QH);
     pl.ngroups = (pl.Cp + CG - 1) / CG;
-    pl.seg[0] = B * pl.qtiles * pl.ngroups;
+    auto pad8 = [](long long n) { return (int)((n + 7) / 8 * 8); };
+    pl.seg[0] = pad8((long long)B * pl.qtiles * pl.ngroups);
     size_t pf = 0;
     for (int l = 0; l < L; ++l) {
         const int hl = H >> l, wl = W >> l;
@@ -535,7 +547,7 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
         const long long est = std::min<long long>(pl.qtiles, side * side);
         pl.nsplit[l] = (int)std::min<long long>(MAXSPLIT, std::max<long long>(1, (est + 11) / 12));
         if (l == 0) pl.nsplit[l] = 1;
-        if (l + 1 <= L) pl.seg[l + 1] = pl.seg[l] + B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups;
+        pl.seg[l + 1] = pl.seg[l] + pad8((long long)B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups);
         pl.poff[l] = pf;
         if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
     }

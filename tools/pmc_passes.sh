@@ -1,16 +1,17 @@
 #!/bin/bash
 # Runs the rocprofv3 PMC passes (one run per pass, as the MI355X guide prescribes) on
 # tools/prof_step.py and leaves per-dispatch CSVs under gpurun_out/pmc/<pass>/.
-# usage: bash tools/pmc_passes.sh [steps]
+# usage: bash tools/pmc_passes.sh [steps] [config] [outdir-name]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 STEPS=${1:-3}
-OUT=$ROOT/gpurun_out/pmc
+CFG=${2:-sintel}
+OUT=$ROOT/gpurun_out/${3:-pmc}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/tools/prof_step.py" "$STEPS" > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/tools/prof_step.py" "$STEPS" "$CFG" > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }
 run fetch FETCH_SIZE TCC_EA0_RDREQ_DRAM_sum &&
