@@ -171,7 +171,7 @@ class InputPadder:
 
 class RAFT(nn.Module):
     def __init__(self, corr_factory, fuse_convc1=False):
-        """fuse_convc1: inference only; the correlation block must offer lookup_conv1x1
+        """fuse_convc1: the correlation block must offer lookup_conv1x1 (differentiable)
         (raft_amd.CorrBlock does): the motion encoder's first 1x1 conv + ReLU then runs inside
         the lookup kernel and the (B, 324, H, W) tensor is never materialised."""
         super().__init__()
@@ -199,7 +199,7 @@ class RAFT(nn.Module):
         preds = []
         for _ in range(iters):
             coords1 = coords1.detach()
-            if self.fuse_convc1 and not torch.is_grad_enabled():
+            if self.fuse_convc1:
                 enc = self.update_block.encoder.convc1
                 corr = corr_fn.lookup_conv1x1(coords1, enc.weight, enc.bias, relu=True)
             else:

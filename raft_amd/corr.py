@@ -281,6 +281,49 @@ class _Lookup(torch.autograd.Function):
         return danchor, dcoords, None, None, None
 
 
+class _LookupConv(torch.autograd.Function):
+    """Fused lookup + 1x1 convolution (+ bias, + ReLU), differentiable.  Forward: one launch
+    (raftcorr_lookup_conv1x1_fwd), the (B, L*rd*rd, H, W) tensor is never stored.  Backward re-creates it with
+    raftcorr_lookup_fwd (a 7 us kernel instead of a 9 MB tensor kept alive per iteration), takes d(weight) and
+    d(bias) from it and sends W^T d(pre) through raftcorr_lookup_bwd into the block's shared gradient pyramid,
+    exactly where an unfused lookup's gradient goes (core/update.py:83,90 on the training path)."""
+
+    @staticmethod
+    def forward(ctx, anchor, coords, weight, bias, blk, relu):
+        out = blk._lookup_conv1x1_nograd(coords, weight, bias, relu)
+        ctx.blk, ctx.relu = blk, relu
+        ctx.save_for_backward(coords, weight, out if relu else None)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        coords, weight, out = ctx.saved_tensors
+        blk, pyr = ctx.blk, ctx.blk._pyr
+        lib = _lib.load()
+        dpre = _f32c(dout)
+        if ctx.relu:
+            dpre = dpre * (out > 0)
+        w2 = weight.reshape(weight.shape[0], -1).float()
+        B, Cout = dpre.shape[:2]
+        dweight = dbias = danchor = None
+        if ctx.needs_input_grad[2]:
+            x = _lookup(pyr, coords, blk.radius, _lib.MODE_CANONICAL)            # recomputed, (B, Cin, H, W)
+            dweight = torch.einsum("bon,bkn->ok", dpre.reshape(B, Cout, -1), x.reshape(B, x.shape[1], -1)).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dbias = dpre.sum(dim=(0, 2, 3))
+        if ctx.needs_input_grad[0]:
+            dx = torch.einsum("ok,bon->bkn", w2, dpre.reshape(B, Cout, -1)).reshape(B, -1, pyr.H, pyr.W).contiguous()
+            with _guard(coords):
+                pyr.grad_buffer()
+                _lib.check(lib.raftcorr_lookup_bwd(pyr.ptrs, pyr.dptrs, pyr.B, pyr.H, pyr.W, pyr.L, blk.radius,
+                                                   coords.data_ptr(), _lib.MODE_CANONICAL, dx.data_ptr(), None,
+                                                   _stream(coords)), "lookup_bwd")
+            danchor = torch.zeros(1, dtype=torch.float32, device=coords.device)
+        return danchor, None, dweight, dbias, None, None
+
+
 class CorrBlock:
     """All-pairs correlation volume + pooled pyramid + radius-r bilinear lookup.
     Drop-in for core/corr.py:12-61 (same constructor defaults: num_levels=2, radius=4).
@@ -376,8 +419,17 @@ class CorrBlock:
         """Canonical lookup fused with a 1x1 convolution (+ bias, + ReLU) over its channels: what
         RAFT's motion encoder does first with the result, `F.relu(self.convc1(corr))`
         (core/update.py:83,90).  coords (B, 2, H, W); weight (Cout, L*rd*rd[, 1, 1]); returns
-        (B, Cout, H, W) without materialising the (B, L*rd*rd, H, W) tensor.  Inference only: no
-        autograd graph is recorded.  The packed weight is cached on this CorrBlock per weight tensor version."""
+        (B, Cout, H, W) without materialising the (B, L*rd*rd, H, W) tensor.  Differentiable w.r.t. the
+        features (through the block's shared gradient pyramid), the weight and the bias; coords are treated as
+        detached (core/raft.py:124).  The packed weight is cached on this CorrBlock per weight tensor version."""
+        if torch.is_grad_enabled() and (self._anchor is not None or weight.requires_grad or
+                                        (bias is not None and bias.requires_grad)):
+            anchor = self._anchor if self._anchor is not None else \
+                torch.zeros(1, dtype=torch.float32, device=coords.device)
+            return _LookupConv.apply(anchor, _f32c(coords.detach()), weight, bias, self, relu)
+        return self._lookup_conv1x1_nograd(coords, weight, bias, relu)
+
+    def _lookup_conv1x1_nograd(self, coords, weight, bias=None, relu=True):
         p = self._pyr
         _require_cuda(coords=coords, weight=weight, **({} if bias is None else {"bias": bias}))
         if coords.device != p.device:

@@ -404,6 +404,42 @@ def test_lookup_fused_with_convc1(case, dev):
     assert torch.equal(got, again)
 
 
+def test_lookup_fused_with_convc1_backward(dev):
+    """Gradients of relu(convc1(lookup)) through CorrBlock.lookup_conv1x1 (two fused lookups + one plain lookup
+    sharing the block's gradient pyramid) against autograd of the oracle's CorrBlock + conv2d: features, weight,
+    bias.  VERDICT r1 item 7 (core/update.py:83,90 is on the training path)."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(21)
+    B, D, H, W, L, r, cout = 2, 32, 19, 27, 4, 4, 96
+    cin = L * (2 * r + 1) ** 2
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    cons = [(rs.rand(B, 2, H, W) * [[[W + 4]], [[H + 4]]] - 2).astype(np.float32) for _ in range(3)]
+    wn = (rs.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32)
+    bn = rs.randn(cout).astype(np.float32)
+    g_out = [rs.randn(B, cout, H, W).astype(np.float32) for _ in range(2)] + [rs.randn(B, cin, H, W).astype(np.float32)]
+
+    def run(device, ours):
+        f1, f2 = torch.from_numpy(f1n).to(device).requires_grad_(True), torch.from_numpy(f2n).to(device).requires_grad_(True)
+        wt, bias = torch.from_numpy(wn).to(device).requires_grad_(True), torch.from_numpy(bn).to(device).requires_grad_(True)
+        cb = CorrBlock(f1, f2, num_levels=L, radius=r) if ours else O.CorrBlockOracle(f1, f2, L, r)
+        outs = []
+        for k in range(2):
+            c = torch.from_numpy(cons[k]).to(device)
+            outs.append(cb.lookup_conv1x1(c, wt, bias, relu=True) if ours
+                        else torch.relu(torch.nn.functional.conv2d(cb(c), wt, bias)))
+        outs.append(cb(torch.from_numpy(cons[2]).to(device)))
+        torch.autograd.backward(outs, [torch.from_numpy(g).to(device) for g in g_out])
+        return [t.grad.cpu().numpy() for t in (f1, f2, wt, bias)], [o.detach().cpu().numpy() for o in outs]
+
+    (g1, g2, gw, gb), outs = run(dev, True)
+    (r1, r2, rw, rb), routs = run("cpu", False)
+    for o, ro in zip(outs, routs):
+        assert rel_err(o, ro) <= TOL
+    assert rel_err(g1, r1) <= GTOL and rel_err(g2, r2) <= GTOL
+    assert rel_err(gw, rw) <= GTOL and rel_err(gb, rb) <= GTOL
+
+
 # ---------------------------------------------------------------------------------------
 # on-the-fly ("alternate") path
 # ---------------------------------------------------------------------------------------
