@@ -205,7 +205,7 @@ class SintelFwd(Workload):
         w = work_of(self.cfg)
         iters = CONFIGS[self.cfg][4]
         build_us, lookup_us = phases_us[0], phases_us[1] / iters
-        traffic = load_profile_json("pmc_traffic.json")
+        traffic = load_profile_json("r02_pmc_traffic_sintel.json") or load_profile_json("pmc_traffic.json")
         kb = frac_entry("corr_build_f32_kernel (+ corr_pack_kernel)", build_us, "mfma", w["build_flops"],
                         MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=w["build_flops"],
                         algorithmic_bytes=w["build_bytes"], hbm_GBs=w["build_bytes"] / build_us / 1e3,
@@ -260,15 +260,19 @@ class KittiAlt(Workload):
         w = work_of(self.cfg)
         iters = CONFIGS[self.cfg][4]
         fwd_us, bwd_us = phases_us[0] / iters, phases_us[1] / iters
-        note = "phase time / lookups: includes the feature pyramid (fwd) and autograd glue (bwd)"
-        k = {"alt_fwd": frac_entry("alt_fwd_kernel", fwd_us, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
+        note = ("phase time / lookups: includes the feature pyramid and packs (fwd) and autograd glue (bwd); the product runs "
+                "on the 16-bit matrix cores (3 fp16 terms), fractions are of the fp32-matrix and HBM peaks of SURVEY 8(d)")
+        tr = load_profile_json("r02_pmc_traffic_kitti.json")
+        k = {"alt_fwd": frac_entry("alt_fwd16_kernel", fwd_us, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
                                    "TFLOP/s", algorithmic_flops=w["alt_flops"], compulsory_bytes=w["alt_bytes"],
                                    hbm_GBs=w["alt_bytes"] / fwd_us / 1e3,
-                                   hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, note=note),
-             "alt_bwd": frac_entry("alt_bwd_kernel", bwd_us, "mfma", w["alt_bwd_flops"], MFMA_F32_PEAK_TFLOPS,
-                                   "TFLOP/s", algorithmic_flops=w["alt_bwd_flops"],
+                                   hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, traffic=tr.get("alt_fwd16_kernel"),
+                                   note=note),
+             "alt_bwd": frac_entry("alt_bwd_kernel (+ range pass, windows, reduce)", bwd_us, "mfma", w["alt_bwd_flops"],
+                                   MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=w["alt_bwd_flops"],
                                    compulsory_bytes=w["alt_bwd_bytes"], hbm_GBs=w["alt_bwd_bytes"] / bwd_us / 1e3,
-                                   hbm_frac=w["alt_bwd_bytes"] / bwd_us / 1e3 / HBM_PEAK_GBS, note=note)}
+                                   hbm_frac=w["alt_bwd_bytes"] / bwd_us / 1e3 / HBM_PEAK_GBS,
+                                   traffic=tr.get("alt_bwd_kernel"), note=note)}
         return k, ("alt_bwd" if bwd_us >= fwd_us else "alt_fwd")
 
 

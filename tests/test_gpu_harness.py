@@ -117,6 +117,9 @@ def test_training_step_gradients_match_reference_corr(dev):
     assert abs(l_ref - l_our) <= 1e-5 * abs(l_ref)
     assert g_ref.keys() == g_our.keys() and any(k.startswith("fnet.") for k in g_ref)
     gmax = max(np.abs(g).max() for g in g_ref.values())
+    worst = 0.0
     for k in g_ref:       # parameters in front of a norm layer have a zero gradient (1e-8 noise): atol
         scale = np.abs(g_ref[k]).max()
-        assert np.abs(g_ref[k] - g_our[k]).max() <= 1e-3 * scale + 1e-5 * gmax, k
+        worst = max(worst, float(np.abs(g_ref[k] - g_our[k]).max() / (scale + 1e-2 * gmax)))
+        assert np.abs(g_ref[k] - g_our[k]).max() <= 1e-4 * scale + 1e-5 * gmax, k
+    print(f"train-step gradients: worst per-parameter difference {worst:.1e} of its scale")

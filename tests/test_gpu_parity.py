@@ -12,8 +12,11 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
+# Bars: the north star's 1e-5 (fp32), forward and backward.  Metric (tests/conftest.py:rel_err): max|a - b| / max|b|.
+# For scale: the reference's own fp32 backward pass is 1.2e-6 .. 2.6e-6 away from the same computation in float64,
+# this library 2e-7 .. 6e-7 (tools/grad_tolerance.py -> profiles/r02_grad_tolerance.json).
 TOL = 1e-5
-GTOL = 2e-5
+GTOL = 1e-5
 FORK = ["F1_fork_fwd", "F2_fork_bwd", "F3_fork_defaults", "F4_fork_edges"]
 CANON = ["C1_canon_fwd_a", "C1_canon_fwd_b", "C2_canon_bwd"]
 
@@ -37,7 +40,7 @@ def test_golden_forward_backward(name, dev):
         out.backward(_t(g["gout"], dev))
         assert rel_err(f1.grad.cpu().numpy(), g["dfmap1"]) <= GTOL
         assert rel_err(f2.grad.cpu().numpy(), g["dfmap2"]) <= GTOL
-        assert rel_err(co.grad.cpu().numpy(), g["dcoords"]) <= 5e-5
+        assert rel_err(co.grad.cpu().numpy(), g["dcoords"]) <= GTOL
 
 
 @pytest.mark.parametrize("shape", [(1, 256, 55, 128), (1, 256, 47, 156), (2, 128, 27, 64),
@@ -107,7 +110,7 @@ def test_other_radii_and_level_counts(case, dev):
     assert got[0].shape == ref[0].shape
     assert rel_err(got[0], ref[0]) <= TOL
     assert rel_err(got[1], ref[1]) <= GTOL and rel_err(got[2], ref[2]) <= GTOL
-    assert rel_err(got[3], ref[3]) <= 5e-5
+    assert rel_err(got[3], ref[3]) <= GTOL
 
 
 def _sintel_inputs():
@@ -729,7 +732,7 @@ def test_k1_kitti_shape_forward_backward(block, dev, record_property):
         assert e_out <= TOL and e_sum <= 1e-6
     assert e1 <= GTOL and e2 <= GTOL and a1 <= 1e-5 and a2 <= 1e-5
     if block != "on_the_fly":
-        assert rel_err(co.grad.cpu().numpy(), g["dcoords"]) <= 5e-5
+        assert rel_err(co.grad.cpu().numpy(), g["dcoords"]) <= GTOL
 
 
 def test_t1_things_shape_12_lookups_forward_backward(dev):

@@ -14,7 +14,7 @@ for cfg in sintel kitti_alt things_train 1080p; do
   echo "bench $cfg ok"
 done
 cd /tmp && export TMPDIR=/tmp
-for cfg in sintel kitti_alt things_train; do
+for cfg in sintel kitti_alt things_train 1080p; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$cfg" -- python3 "$ROOT/bench.py" --config $cfg --no-extras --no-cpu-baseline > "$OUT/prof_$cfg.log" 2>&1 || { echo "prof $cfg failed"; tail -20 "$OUT/prof_$cfg.log"; exit 1; }
   echo "prof $cfg ok"
 done
