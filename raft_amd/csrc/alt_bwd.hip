@@ -10,7 +10,7 @@
 // windows touch, one that owns an 8x8 tile of level-l targets walks the query tiles whose windows touch it.  Either
 // way one STEP is the same dense 64 x 64 block: build G[q][u] from the 2x2-filtered d(out) window of every query
 // (zero where u is not a tap of q), multiply it with the partner tile's features on the 16-bit matrix cores and keep
-// the owner's 64 x 128 slice of the gradient in registers until it is stored -- once, by its only writer.
+// the owner's 64 x 256 slice of the gradient in registers until it is stored -- once, by its only writer.
 //
 //  * Operands: the features are packed once per frame pair TILE-MAJOR (raftcorr_alt_pack_tiles): per 8x8 pixel tile
 //    and channel 256 bytes = [hi | lo] fp16 pieces of the 64 pixels (the fp16x2 scheme of alt_fwd16.hip: maps scaled
@@ -21,7 +21,7 @@
 //    same way; the product is hi*hi + hi*lo + lo*hi in fp32 accumulators, unscaled exactly at the end.
 //  * LDS images have 256-byte rows (row = query / target / channel, 16 slots); slot j of row r lives at j ^ (r & 15),
 //    which makes the ds_read_b128 fragment reads conflict-free (the DMA applies the XOR to its source address).
-//  * d(fmap1): workgroup = (query tile, 128-channel group), all levels -> stored directly.  d(fmap2_l): workgroup =
+//  * d(fmap1): workgroup = (query tile, 256-channel group), all levels -> stored directly.  d(fmap2_l): workgroup =
 //    (target tile, channel group, split s of the list of overlapping query tiles); level 0 stores directly, the
 //    coarser levels (few target tiles, each touched by hundreds of query tiles) write per-split partial tiles that a
 //    small second kernel adds in a fixed order.  The list comes from a table of per-(level, query tile) window
@@ -34,8 +34,10 @@ namespace raftcorr {
 
 namespace {
 
-constexpr int NCB = 4;                            // MFMA column blocks (32 channels each) per workgroup
-constexpr int CG = 32 * NCB;                      // channels per workgroup
+constexpr int NCB = 4;                            // MFMA column blocks (32 channels each) per staged partner slice
+constexpr int CG = 32 * NCB;                      // channels per slice
+constexpr int NH = 2;                             // slices per workgroup: G is built once per step and multiplied with each
+constexpr int GW = NH * CG;                       // channels per workgroup
 constexpr int IMG_A = TQ * 16;                    // uint4 slots of the G image  [64 rows][16 slots]
 constexpr int IMG_B = CG * 16;                    // uint4 slots of the partner image [CG channel rows][16 slots]
 constexpr int MAXSPLIT = 32;
@@ -59,6 +61,7 @@ struct AltBwdArgs {
                                                   // every segment is padded to a multiple of 8 (one share per XCD)
     int B, C, Cp, H, W, L, r;
     int qtx, qtiles, ngroups;
+    int gw;                                       // channels per workgroup: CG or GW (see make_plan)
     float sqrt_c;
 };
 
@@ -304,15 +307,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // are restrict-qualified parameters: after inlining, the DMA destination and the reads / writes of the other regions
 // carry distinct alias scopes, so hipcc does not wait for the DMA in front of the first LDS access of make_g (the
 // construction of alt_fwd16.hip and build_pyramid.hip).  `prefetch()` may start global loads (no LDS access) that
-// stay in flight over the step; `keep` = how many of them (vector-memory loads complete in order: waiting until only
-// `keep` are outstanding means the older DMA has landed).
+// stay in flight over the step; keep25 = the 25 loads of dtile_issue (vector-memory loads complete in order: waiting
+// until only those are outstanding means the older DMA has landed).  `rows` = channels of this workgroup (<= GW): the
+// G image is built once and multiplied with one CG-channel slice of the partner after the other.
 template <bool TR, class F>
 __device__ __forceinline__ void pair_step(const uint4* __restrict__ src, int rows, uint4* __restrict__ Bimg,
                                           uint4* __restrict__ Aimg, const float* __restrict__ D, const BwdSh& sh,
-                                          int ty0, int tx0, int rd, float sg, v16f (&acc)[NCB / 2],
+                                          int ty0, int tx0, int rd, float sg, v16f (&acc)[NH][NCB / 2],
                                           int mb, int nb0, int l31, int kh, int wave, int lane, bool keep25, F prefetch)
 {
-    stage_partner(src, Bimg, rows, wave, lane);
+    stage_partner(src, Bimg, min(rows, CG), wave, lane);
     asm volatile("" ::: "memory");                           // the DMA stays older than the prefetch
     prefetch();
 #if !defined(RC_LAB_BWD_NOG)
@@ -322,8 +326,19 @@ __device__ __forceinline__ void pair_step(const uint4* __restrict__ src, int row
     else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 #if !defined(RC_LAB_BWD_NOMFMA)
-    mfma_step<TR>(Aimg, Bimg, acc, mb, nb0, l31, kh);
+    mfma_step<TR>(Aimg, Bimg, acc[0], mb, nb0, l31, kh);
 #endif
+#pragma unroll
+    for (int h = 1; h < NH; ++h) {
+        if (rows <= h * CG) break;                           // workgroup-uniform
+        lds_barrier();                                       // the slice in LDS has been multiplied
+        stage_partner(src + h * CG * 16, Bimg, min(rows - h * CG, CG), wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the prefetch is older than this DMA and has had the step to land)
+        lds_barrier();
+#if !defined(RC_LAB_BWD_NOMFMA)
+        mfma_step<TR>(Aimg, Bimg, acc[h], mb, nb0, l31, kh);
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -347,11 +362,13 @@ void alt_bwd_kernel(AltBwdArgs p)
     const size_t P = (size_t)p.H * p.W;
     const int wg = blockIdx.x;
 
-    v16f acc[NCB / 2];
+    v16f acc[NH][NCB / 2];
 #pragma unroll
-    for (int j = 0; j < NCB / 2; ++j)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        for (int j = 0; j < NCB / 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[h][j][i] = 0.f;
 
 #if defined(RC_LAB_BWD_ONLY1)
     if (wg >= p.seg[0]) return;
@@ -368,7 +385,7 @@ void alt_bwd_kernel(AltBwdArgs p)
         const int item = banded(wg, p.seg[0]);
         if (item >= p.B * p.qtiles * p.ngroups) return;      // padding of the segment (whole workgroup)
         const int g = item % p.ngroups, rest = item / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
-        const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
+        const int rows = min(p.gw, p.Cp - g * p.gw);             // channels of this workgroup (a multiple of 32)
         DTile dt;
         dtile_issue(p, dt, b, 0, tile, rd2, wave);
         for (int l = 0; l < p.L; ++l) {
@@ -379,10 +396,10 @@ void alt_bwd_kernel(AltBwdArgs p)
             __syncthreads();
             if (box.x > box.y || box.z > box.w) continue;
             const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
-            const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * CG) * 16;
+            const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * p.gw) * 16;
             for (int ty = box.z >> 3; ty <= box.w >> 3; ++ty)
                 for (int tx = box.x >> 3; tx <= box.y >> 3; ++tx) {
-                    pair_step<false>(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, ncb * 32, Bimg, Aimg, D, sh, ty * 8, tx * 8, rd, sg,
+                    pair_step<false>(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, rows, Bimg, Aimg, D, sh, ty * 8, tx * 8, rd, sg,
                                      acc, mb, nb0, l31, kh, wave, lane, false, [] {});
                     lds_barrier();                           // images are free again
                 }
@@ -390,14 +407,15 @@ void alt_bwd_kernel(AltBwdArgs p)
         const float unscale = ldexpf(1.0f, -(eg + e2));
         float* __restrict__ out = p.df1 + (size_t)b * P * p.C;
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j) {
-            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
-            if (nb0 + 2 * j < ncb && c < p.C) {
+        for (int hj = 0; hj < NH * (NCB / 2); ++hj) {
+            const int h = hj / (NCB / 2), j = hj % (NCB / 2);
+            const int c = g * p.gw + h * CG + (nb0 + 2 * j) * 32 + l31;
+            if (h * CG < rows && c < p.C) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
                     const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
-                    if (gy < p.H && gx < p.W) out[((size_t)gy * p.W + gx) * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
+                    if (gy < p.H && gx < p.W) out[((size_t)gy * p.W + gx) * p.C + c] = (acc[h][j][i] * unscale) / p.sqrt_c;
                 }
             }
         }
@@ -416,10 +434,10 @@ void alt_bwd_kernel(AltBwdArgs p)
     if (ttiles >= 8 * nsplit) { s = idx % nsplit; idx /= nsplit; tt = idx % ttiles; idx /= ttiles; }    // bands of target tiles
     else                      { tt = idx % ttiles; idx /= ttiles; s = idx % nsplit; idx /= nsplit; }    // bands of query tiles
     const int b = idx;
-    const int ncb = min(NCB, (p.Cp - g * CG) >> 5);
+    const int rows = min(p.gw, p.Cp - g * p.gw);                 // channels of this workgroup (a multiple of 32)
     const int ty0 = (tt / ttx) * 8, tx0 = (tt % ttx) * 8;
     const int4* __restrict__ boxes = p.boxes + ((size_t)b * p.L + l) * p.qtiles;
-    const uint4* __restrict__ f1b = p.f1t + ((size_t)b * p.qtiles * p.Cp + g * CG) * 16;
+    const uint4* __restrict__ f1b = p.f1t + ((size_t)b * p.qtiles * p.Cp + g * p.gw) * 16;
 
     auto touches = [&](int e) {
         const int4 bx = boxes[min(e, p.qtiles - 1)];
@@ -453,7 +471,7 @@ void alt_bwd_kernel(AltBwdArgs p)
             dtile_commit(p, dt, D, sh, b, l, qt, rd2, wave);
             lds_barrier();
             // the 25 loads of dtile_issue (24 channels + the windows) fly under this step and the start of the next
-            pair_step<true>(f1b + (size_t)qt * p.Cp * 16, ncb * 32, Bimg, Aimg, D, sh, ty0, tx0, rd, sg,
+            pair_step<true>(f1b + (size_t)qt * p.Cp * 16, rows, Bimg, Aimg, D, sh, ty0, tx0, rd, sg,
                             acc, mb, nb0, l31, kh, wave, lane, more, [&] { if (more) dtile_issue(p, dt, b, l, qt_next, rd2, wave); });
         }
         pos += chunk_n;
@@ -465,27 +483,29 @@ void alt_bwd_kernel(AltBwdArgs p)
         const float unscale = ldexpf(1.0f, -(eg + e1));
         float* __restrict__ out = p.df2[l] + (size_t)b * Hl * Wl * p.C;
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j) {
-            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
-            if (nb0 + 2 * j < ncb && c < p.C) {
+        for (int hj = 0; hj < NH * (NCB / 2); ++hj) {
+            const int h = hj / (NCB / 2), j = hj % (NCB / 2);
+            const int c = g * p.gw + h * CG + (nb0 + 2 * j) * 32 + l31;
+            if (h * CG < rows && c < p.C) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int u = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
                     const int Y = ty0 + (u >> 3), X = tx0 + (u & 7);
-                    if (Y < Hl && X < Wl) out[((size_t)Y * Wl + X) * p.C + c] = (acc[j][i] * unscale) / p.sqrt_c;
+                    if (Y < Hl && X < Wl) out[((size_t)Y * Wl + X) * p.C + c] = (acc[h][j][i] * unscale) / p.sqrt_c;
                 }
             }
         }
     } else {
         float* __restrict__ out = p.partial + p.poff[l] + ((((size_t)b * ttiles + tt) * nsplit + s) * TQ) * p.Cp;
 #pragma unroll
-        for (int j = 0; j < NCB / 2; ++j) {
-            const int c = g * CG + (nb0 + 2 * j) * 32 + l31;
-            if (nb0 + 2 * j < ncb) {
+        for (int hj = 0; hj < NH * (NCB / 2); ++hj) {
+            const int h = hj / (NCB / 2), j = hj % (NCB / 2);
+            const int c = g * p.gw + h * CG + (nb0 + 2 * j) * 32 + l31;
+            if (h * CG < rows && c < p.Cp) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int u = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    out[(size_t)u * p.Cp + c] = acc[j][i];
+                    out[(size_t)u * p.Cp + c] = acc[h][j][i];
                 }
             }
         }
@@ -522,7 +542,7 @@ void alt_bwd_reduce_kernel(AltBwdArgs p)
 }
 
 struct BwdPlan {
-    int Cp, qtx, qtiles, ngroups;
+    int Cp, qtx, qtiles, ngroups, gw;
     int nsplit[RAFTCORR_MAX_LEVELS], ttiles[RAFTCORR_MAX_LEVELS], seg[RAFTCORR_MAX_LEVELS + 1];
     size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
     size_t off_boxes, off_wins, off_partial, bytes;
@@ -535,7 +555,11 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
     pl.Cp = (C + 31) / 32 * 32;
     pl.qtx = (W + QW - 1) / QW;
     pl.qtiles = pl.qtx * ((H + QH - 1) / QH);
-    pl.ngroups = (pl.Cp + CG - 1) / CG;
+    // Channels per workgroup.  GW: the G image of a step is built once and multiplied with two partner slices (half the
+    // construction work, the kernel's bottleneck) -- when the query tiles alone fill the chip; with few tiles (KITTI at
+    // B = 1: 120) twice as many workgroups with one slice each balance better (measured both ways at both sizes).
+    pl.gw = (long long)B * pl.qtiles >= 256 ? GW : CG;
+    pl.ngroups = (pl.Cp + pl.gw - 1) / pl.gw;
     auto pad8 = [](long long n) { return (int)((n + 7) / 8 * 8); };
     pl.seg[0] = pad8((long long)B * pl.qtiles * pl.ngroups);
     size_t pf = 0;
@@ -602,7 +626,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     a.wins = (int4*)((char*)workspace + pl.off_wins);
     a.partial = (float*)((char*)workspace + pl.off_partial);
     a.B = B; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
-    a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups;
+    a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups; a.gw = pl.gw;
     a.sqrt_c = sqrtf((float)C);
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc = launch_maxabs1(dout, (size_t)B * L * rd2 * H * W, (float*)workspace, s);
