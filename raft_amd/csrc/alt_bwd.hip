@@ -153,9 +153,6 @@ __device__ __forceinline__ void store_g(uint4* img, int row, int slot, int key, 
 // LDS slot j of row c receives source slot j ^ (c & 15)
 __device__ __forceinline__ void stage_partner(const uint4* __restrict__ src, uint4* img, int rows, int wave, int lane)
 {
-#if defined(RC_LAB_BWD_NODMA)
-    return;
-#endif
     for (int r4 = wave; r4 * 4 < rows; r4 += 4) {
         const int row = r4 * 4 + (lane >> 4);
         glds16(src + row * 16 + ((lane & 15) ^ (row & 15)), img + r4 * 64);
@@ -370,11 +367,6 @@ void alt_bwd_kernel(AltBwdArgs p)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[h][j][i] = 0.f;
 
-#if defined(RC_LAB_BWD_ONLY1)
-    if (wg >= p.seg[0]) return;
-#elif defined(RC_LAB_BWD_ONLY2)
-    if (wg < p.seg[0]) return;
-#endif
     // Workgroup id -> work item, XCD-aware: the hardware deals workgroups round-robin over the 8 XCDs, each with its
     // own L2.  Inside a segment XCD x gets the x-th eighth of the item list, and the list is ordered so that an eighth
     // is a band of image rows (tiles row-major; for the split levels the split index, i.e. a band of query tiles,

@@ -7,7 +7,7 @@ iterations), sequence loss, AdamW + StepLR + gradient clipping as core/train_ori
 and runs on RCCL over xGMI (backend "nccl").  The reference uses single-process nn.DataParallel
 (train.py:342), which is not replicated.
 
-    python tools/train_step.py [--steps K] [--warmup W] [--corr ours|stock|alt] [--batch 6] [--iters 12]
+    python tools/train_step.py [--steps K] [--warmup W] [--corr ours|ours_fused|stock|alt] [--batch 6] [--iters 12]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P tools/train_step.py ...
 Prints one JSON line from rank 0: image pairs/s over all ranks, ms per step, and the share of the
@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--corr", default="ours", choices=["ours", "stock", "alt"])
+    ap.add_argument("--corr", default="ours", choices=["ours", "ours_fused", "stock", "alt"])
     ap.add_argument("--batch", type=int, default=6)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--size", type=int, nargs=2, default=[400, 720])
@@ -59,7 +59,9 @@ def main():
         dist.init_process_group("nccl" if on_gpu else "gloo", **({"device_id": dev} if on_gpu else {}))
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = RAFT(corr_factory(args.corr)).to(dev).train()
+    # ours_fused: lookup fused with the motion encoder's convc1 + ReLU (differentiable, raft_amd/corr.py:_LookupConv)
+    model = RAFT(corr_factory("ours" if args.corr == "ours_fused" else args.corr),
+                 fuse_convc1=args.corr == "ours_fused").to(dev).train()
     for m in model.modules():                              # freeze_bn (core/raft.py:60-63), as every stage after chairs
         if isinstance(m, nn.BatchNorm2d):
             m.eval()
