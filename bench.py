@@ -482,7 +482,7 @@ def extras_things(torch, wl, dev):
         if "fold" in name:
             out["profile:" + name] = frac_entry(name, us, "hbm", w["fold_bytes"], HBM_PEAK_GBS, "GB/s",
                                                 source="profiles/r02_things_kernels.json")
-        elif "gemm" in name:
+        elif "gemm" in name and "reduce" not in name:
             out["profile:" + name] = frac_entry(name, us, "mfma", w["gemm_flops"], MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                                                 source="profiles/r02_things_kernels.json")
     return out
