@@ -760,6 +760,37 @@ def test_t1_things_shape_12_lookups_forward_backward(dev):
     assert e1 <= GTOL and e2 <= GTOL and a1 <= 1e-5 and a2 <= 1e-5
 
 
+def test_t1_things_shape_on_the_fly(dev):
+    """The T1 case through AlternateCorrBlock: B * query tiles = 504 >= 256, so the backward kernel
+    runs with 256-channel groups (two partner slices per step) — the branch the KITTI-sized cases do
+    not reach.  The expected values are the all-pairs reference's (the two reference paths agree to
+    the coordinate round trip)."""
+    from raft_amd import AlternateCorrBlock
+    I = _full_inputs()
+    g = load_golden("T1_things")
+    f1n, f2n, coords, goutn, wts = I.t1_inputs()
+    f1, f2, gout = _t(f1n, dev, True), _t(f2n, dev, True), _t(goutn, dev)
+    B, _, H, W = f1n.shape
+    cb = AlternateCorrBlock(f1, f2, num_levels=I.L, radius=I.R)
+    loss = 0
+    for k, (c, wk) in enumerate(zip(coords, wts)):
+        o = cb(_t(c, dev))
+        loss = loss + wk * (o * gout).sum()
+        if k in (0, 5, 11):
+            got = o.detach().permute(0, 2, 3, 1).reshape(B * H * W, -1)[torch.from_numpy(g["rows"]).to(dev)]
+            assert rel_err(got.cpu().numpy(), g[f"out_rows_{k}"]) <= TOL, k
+    loss.backward()
+    e1, a1 = _grad_err(f1.grad, g, "dfmap1")
+    e2, a2 = _grad_err(f2.grad, g, "dfmap2")
+    print(f"T1 on the fly: dfmap1 {e1:.2e} dfmap2 {e2:.2e}")
+    assert e1 <= GTOL and e2 <= GTOL and a1 <= 1e-5 and a2 <= 1e-5
+    # and the same bits on a second pass
+    f1b, f2b = _t(f1n, dev, True), _t(f2n, dev, True)
+    cb2 = AlternateCorrBlock(f1b, f2b, num_levels=I.L, radius=I.R)
+    sum(wk * (cb2(_t(c, dev)) * gout).sum() for c, wk in zip(coords, wts)).backward()
+    assert torch.equal(f1.grad, f1b.grad) and torch.equal(f2.grad, f2b.grad)
+
+
 @pytest.mark.parametrize("block", ["fp32", "fp16x2", "bf16x3", "bf16", "bf16+bf16vol", "fp16x2+fp16vol", "on_the_fly"])
 def test_p1_1080p_fractional_coordinates(block, dev):
     """configs[4]: 136x240 at FRACTIONAL coordinates: 128 sampled queries whose volume rows the
