@@ -503,7 +503,10 @@ def test_alternate_corr_block_matches_canonical_reference(name, dev):
 
 
 @pytest.mark.parametrize("case", [(1, 40, 13, 19, 3, 3, "wild"), (2, 32, 12, 21, 2, 5, "smooth"),
-                                  (1, 64, 24, 40, 4, 4, "wild"), (1, 7, 9, 10, 2, 1, "outside")])
+                                  (1, 64, 24, 40, 4, 4, "wild"), (1, 7, 9, 10, 2, 1, "outside"),
+                                  # B * query tiles >= 256: the backward runs 256-channel groups; 40 channels leave the
+                                  # second slice empty, 136 leave it 8 channels (+ padding), 300 need a second group
+                                  (4, 40, 60, 64, 3, 5, "wild"), (5, 136, 52, 60, 2, 3, "smooth"), (8, 300, 41, 47, 2, 4, "smooth")])
 def test_alternate_corr_block_edge_cases(case, dev):
     """Tile kernels of the on-the-fly path against the oracle's canonical CorrBlock (fwd + bwd):
     channel counts that are not a multiple of the staged chunk, ragged query tiles, incoherent
