@@ -434,7 +434,7 @@ def extras_kitti(torch, wl, dev):
                                                                       stream))
             tb = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(gblk._t1.data_ptr(), gblk._t2ptrs, gblk._scales.data_ptr(),
                                                                       B, H, W, D, LEVELS, RADIUS, c.data_ptr(), gout.data_ptr(),
-                                                                      d1.data_ptr(), dlv, work.data_ptr(), wb, stream))
+                                                                      d1.data_ptr(), dlv, 0, work.data_ptr(), wb, stream))
             out["alt_fwd_" + tag] = frac_entry("alt_fwd16_kernel", tf, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
                                                "TFLOP/s", hbm_GBs=w["alt_bytes"] / tf / 1e3,
                                                hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS,

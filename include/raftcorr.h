@@ -241,7 +241,9 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
  *                         fmap2 ((B,C,H>>l,W>>l)); scales: as for the forward call; coords (B,2,H,W); dout
  *                         (B, L*rd*rd, H, W); dfmap1 (B,H,W,C) and dfmap2_levels[l] (B,H_l,W_l,C) float32 NHWC (the
  *                         layout of the reference kernel's gradients, correlation_kernel.cu:304-306), fully
- *                         overwritten; workspace: raftcorr_alt_lookup_bwd_workspace_bytes(...) bytes of caller-allocated
+ *                         overwritten when accumulate == 0 and added to (every element read and written by its one
+ *                         writer, so still reproducible) when accumulate != 0: the gradients of the 12 lookups of one
+ *                         frame pair sum up in place, with no separate additions; workspace: raftcorr_alt_lookup_bwd_workspace_bytes(...) bytes of caller-allocated
  *                         device memory, 256-byte aligned, contents don't-care before and after.
  *                         Arithmetic: fp16x2 split operands (features as packed; g scaled by a power of two taken from
  *                         max|dout|), three fp16 MFMA terms, fp32 accumulation: fp32-grade (gradient parity <= 2e-5). */
@@ -252,7 +254,7 @@ int64_t raftcorr_alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int 
 int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels, const float* scales,
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, const float* dout,
-                            float* dfmap1, float* const* dfmap2_levels,
+                            float* dfmap1, float* const* dfmap2_levels, int accumulate,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

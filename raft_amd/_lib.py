@@ -63,7 +63,7 @@ _SIGNATURES = {
     "raftcorr_alt_pack_tiles": ([_c_fp] + [_c_int] * 4 + [_c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_bwd_workspace_bytes": ([_c_int] * 6, ctypes.c_int64),
     "raftcorr_alt_lookup_bwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
-                                [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
+                                [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_fp, ctypes.c_int64,
                                  ctypes.c_void_p], _c_int),
 }
 

@@ -187,7 +187,8 @@ def _build(fmap1, fmap2, pyr, precision="fp32"):
 class _BuildPyramid(torch.autograd.Function):
     """fmap1, fmap2 -> (packed pyramid, anchor).  The anchor is a 1-element tensor that every
     lookup takes as an input: it carries the graph edge lookups -> build without a dense
-    gradient per lookup (the lookups write into pyr.dflat and return a zero anchor gradient)."""
+    gradient per lookup (the lookups write into pyr.dflat and return no anchor gradient at all: the
+    engine runs this node once all of them have run, with danchor = None)."""
 
     @staticmethod
     def forward(ctx, fmap1, fmap2, pyr, precision):
@@ -277,8 +278,8 @@ class _Lookup(torch.autograd.Function):
                                                coords.data_ptr(), ctx.mode, dout.data_ptr(),
                                                dcoords.data_ptr() if need_co else None,
                                                _stream(coords)), "lookup_bwd")
-        danchor = torch.zeros(1, dtype=torch.float32, device=coords.device) if need_vol else None
-        return danchor, dcoords, None, None, None
+        # no gradient tensor for the anchor: the build node runs once every lookup of the pass has, whatever they return
+        return None, dcoords, None, None, None
 
 
 class _LookupConv(torch.autograd.Function):
@@ -307,7 +308,7 @@ class _LookupConv(torch.autograd.Function):
             dpre = dpre * (out > 0)
         w2 = weight.reshape(weight.shape[0], -1).float()
         B, Cout = dpre.shape[:2]
-        dweight = dbias = danchor = None
+        dweight = dbias = None
         if ctx.needs_input_grad[2]:
             x = _lookup(pyr, coords, blk.radius, _lib.MODE_CANONICAL)            # recomputed, (B, Cin, H, W)
             dweight = torch.einsum("bon,bkn->ok", dpre.reshape(B, Cout, -1), x.reshape(B, x.shape[1], -1)).reshape(weight.shape)
@@ -320,8 +321,7 @@ class _LookupConv(torch.autograd.Function):
                 _lib.check(lib.raftcorr_lookup_bwd(pyr.ptrs, pyr.dptrs, pyr.B, pyr.H, pyr.W, pyr.L, blk.radius,
                                                    coords.data_ptr(), _lib.MODE_CANONICAL, dx.data_ptr(), None,
                                                    _stream(coords)), "lookup_bwd")
-            danchor = torch.zeros(1, dtype=torch.float32, device=coords.device)
-        return danchor, None, dweight, dbias, None, None
+        return None, None, dweight, dbias, None, None
 
 
 class CorrBlock:
@@ -513,15 +513,64 @@ def _alt_forward(blk, coords):
     return out
 
 
-class _AltLookup(torch.autograd.Function):
-    """All levels of the on-the-fly correlation in one launch (forward) and its gradient w.r.t. the features
-    (raftcorr_alt_lookup_bwd: tile-major packed features, no atomics, bit-reproducible).  fmap1 and the fmap2
-    levels are graph inputs only: the kernels read the block's packed copies."""
+class _AltGradState:
+    """Gradient sums of one AlternateCorrBlock (NHWC: d fmap1, d fmap2 level 0, ..).  A separate object so that the
+    anchor's autograd node does not hold the block (which holds the anchor)."""
+
+    def __init__(self, shape, num_levels, device):
+        self.shape, self.L, self.device = shape, num_levels, device
+        self.acc = self.ptrs = self.task = None
+
+    def buffers(self):
+        """(sums, first) for the backward pass that is running now; `first`: nothing of this pass is in them yet (the
+        kernel then overwrites instead of adding -- no zero fill).  What an earlier pass left behind without reaching
+        the features is dropped (cf. _Pyramid.grad_buffer)."""
+        task = _graph_task_id()
+        first = self.acc is None or self.task != task
+        if self.acc is None:
+            B, C, H, W = self.shape
+            self.acc = [torch.empty(B, H, W, C, dtype=torch.float32, device=self.device)] + \
+                       [torch.empty(B, H >> l, W >> l, C, dtype=torch.float32, device=self.device) for l in range(self.L)]
+            self.ptrs = _lib.ptr_array(self.acc[1:])
+        self.task = task
+        return self.acc, first
+
+    def take(self):
+        acc = self.acc if self.acc is not None and self.task == _graph_task_id() else None
+        self.acc = self.ptrs = self.task = None                 # handed to autograd: the next pass gets new buffers
+        return acc
+
+
+class _AltFeatures(torch.autograd.Function):
+    """fmap1 and the fmap2 levels -> anchor.  Like _BuildPyramid's anchor: a 1-element tensor that every lookup of the
+    block takes as an input.  The lookups' backward passes add their feature gradients into the block's accumulators
+    in place (raftcorr_alt_lookup_bwd with accumulate = 1: one kernel, no separate additions, no dense gradient per
+    lookup handed to autograd) and this node, which runs after all of them, hands the sums over."""
 
     @staticmethod
-    def forward(ctx, coords, blk, fmap1, *fmap2_levels):
+    def forward(ctx, state, fmap1, *fmap2_levels):
+        ctx.state = state
+        ctx.shapes = [tuple(fmap1.shape)] + [tuple(t.shape) for t in fmap2_levels]
+        ctx.set_materialize_grads(False)
+        return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, danchor):
+        acc = ctx.state.take()
+        if acc is None:                                         # no lookup of this backward pass reached the features
+            return (None,) * (1 + len(ctx.shapes))
+        return (None, *[t.permute(0, 3, 1, 2) for t in acc])    # NHWC sums, handed over as NCHW views
+
+
+class _AltLookup(torch.autograd.Function):
+    """All levels of the on-the-fly correlation in one launch (forward) and its gradient w.r.t. the features
+    (raftcorr_alt_lookup_bwd: tile-major packed features, no atomics, bit-reproducible).  The kernels read the
+    block's packed copies; the graph edge to the features is the block's anchor (_AltFeatures)."""
+
+    @staticmethod
+    def forward(ctx, anchor, coords, blk):
         ctx.blk = blk
-        ctx.shapes = [tuple(t.shape) for t in fmap2_levels]
         ctx.save_for_backward(coords)
         return _alt_forward(blk, coords)
 
@@ -534,18 +583,16 @@ class _AltLookup(torch.autograd.Function):
         B, C, H, W = blk._shape
         L = blk.num_levels
         dout = _f32c(dout)
-        dev = coords.device
-        d1 = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)             # NHWC, fully overwritten
-        d2 = [torch.empty(b, h, w, c, dtype=torch.float32, device=dev) for (b, c, h, w) in ctx.shapes]
-        wbytes = lib.raftcorr_alt_lookup_bwd_workspace_bytes(B, H, W, C, L, blk.radius)
-        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        acc, first = blk._gstate.buffers()
+        work = blk._bwd_workspace()
         with _guard(coords):
             _lib.check(lib.raftcorr_alt_lookup_bwd(blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
                                                    blk.radius, coords.data_ptr(), dout.data_ptr(),
-                                                   d1.data_ptr(), _lib.ptr_array(d2), work.data_ptr(), wbytes,
-                                                   _stream(coords)), "alt_lookup_bwd")
+                                                   acc[0].data_ptr(), blk._gstate.ptrs, 0 if first else 1,
+                                                   work.data_ptr(), work.numel(), _stream(coords)), "alt_lookup_bwd")
         # coords gradient: the reference kernel never writes it (correlation_kernel.cu:307)
-        return (None, None, d1.permute(0, 3, 1, 2), *[t.permute(0, 3, 1, 2) for t in d2])
+        # (no gradient tensor for the anchor: _AltFeatures.backward runs once every lookup of the pass has)
+        return None, None, None
 
 
 class AlternateCorrBlock:
@@ -601,7 +648,7 @@ class AlternateCorrBlock:
             self._p2 = [pack(t, self._scales.data_ptr() + 128 * 4) for t in f2]
         self._p2ptrs = _lib.ptr_array(self._p2)
         self._grad = torch.is_grad_enabled() and (self.pyramid[0][0].requires_grad or self.pyramid[0][1].requires_grad)
-        self._t1 = self._t2 = self._t2ptrs = None               # tile-major packed copies, for the backward pass only
+        self._t1 = self._t2 = self._t2ptrs = self._anchor = None    # tile-major packed copies, for the backward pass only
         if self._grad:
             with _guard(f1):
                 def pack_tiles(t, scale_ptr):
@@ -615,6 +662,17 @@ class AlternateCorrBlock:
                 self._t1 = pack_tiles(f1, self._scales.data_ptr())
                 self._t2 = [pack_tiles(t, self._scales.data_ptr() + 128 * 4) for t in f2]
             self._t2ptrs = _lib.ptr_array(self._t2)
+            self._gstate = _AltGradState(self._shape, num_levels, dev)
+            self._anchor = _AltFeatures.apply(self._gstate, self.pyramid[0][0],
+                                              *[self.pyramid[i][1] for i in range(num_levels)])
+        self._work = None                                       # workspace of the backward kernels, shared by the lookups
+
+    def _bwd_workspace(self):
+        if self._work is None:
+            B, C, H, W = self._shape
+            nbytes = _lib.load().raftcorr_alt_lookup_bwd_workspace_bytes(B, H, W, C, self.num_levels, self.radius)
+            self._work = torch.empty(nbytes, dtype=torch.uint8, device=self._p1.device)
+        return self._work
 
     def __call__(self, coords):
         _require_cuda(coords=coords)
@@ -625,5 +683,5 @@ class AlternateCorrBlock:
             raise RuntimeError(f"AlternateCorrBlock: coords must be ({B}, 2, {H}, {W}); got {tuple(coords.shape)}")
         coords = _f32c(coords).detach()
         if self._grad and torch.is_grad_enabled():
-            return _AltLookup.apply(coords, self, self.pyramid[0][0], *[self.pyramid[i][1] for i in range(self.num_levels)])
+            return _AltLookup.apply(self._anchor, coords, self)
         return _alt_forward(self, coords)

@@ -62,6 +62,7 @@ struct AltBwdArgs {
     int B, C, Cp, H, W, L, r;
     int qtx, qtiles, ngroups;
     int gw;                                       // channels per workgroup: CG or GW (see make_plan)
+    int accumulate;                               // != 0: df1 / df2 += (same single writer per element), else overwritten
     float sqrt_c;
 };
 
@@ -407,7 +408,12 @@ void alt_bwd_kernel(AltBwdArgs p)
                 for (int i = 0; i < 16; ++i) {
                     const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
                     const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
-                    if (gy < p.H && gx < p.W) out[((size_t)gy * p.W + gx) * p.C + c] = (acc[h][j][i] * unscale) / p.sqrt_c;
+                    if (gy < p.H && gx < p.W) {
+                        float* o = out + ((size_t)gy * p.W + gx) * p.C + c;
+                        float v = (acc[h][j][i] * unscale) / p.sqrt_c;
+                        if (p.accumulate) v += *o;
+                        *o = v;
+                    }
                 }
             }
         }
@@ -483,7 +489,12 @@ void alt_bwd_kernel(AltBwdArgs p)
                 for (int i = 0; i < 16; ++i) {
                     const int u = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
                     const int Y = ty0 + (u >> 3), X = tx0 + (u & 7);
-                    if (Y < Hl && X < Wl) out[((size_t)Y * Wl + X) * p.C + c] = (acc[h][j][i] * unscale) / p.sqrt_c;
+                    if (Y < Hl && X < Wl) {
+                        float* o = out + ((size_t)Y * Wl + X) * p.C + c;
+                        float v = (acc[h][j][i] * unscale) / p.sqrt_c;
+                        if (p.accumulate) v += *o;
+                        *o = v;
+                    }
                 }
             }
         }
@@ -530,7 +541,11 @@ void alt_bwd_reduce_kernel(AltBwdArgs p)
     const float r[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (4 * c4 + j < p.C) out[j] = (r[j] * unscale) / p.sqrt_c;
+        if (4 * c4 + j < p.C) {
+            float v = (r[j] * unscale) / p.sqrt_c;
+            if (p.accumulate) v += out[j];
+            out[j] = v;
+        }
 }
 
 struct BwdPlan {
@@ -595,7 +610,7 @@ size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r)
 }
 
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
-                            int r, const float* coords, const float* dout, float* df1, float* const* df2,
+                            int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
                             void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: radius %d > 7", r);
@@ -620,6 +635,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     a.B = B; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
     a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups; a.gw = pl.gw;
     a.sqrt_c = sqrtf((float)C);
+    a.accumulate = accumulate;
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc = launch_maxabs1(dout, (size_t)B * L * rd2 * H * W, (float*)workspace, s);
     if (rc) return rc;

@@ -364,7 +364,7 @@ int64_t raftcorr_alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int 
 int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels, const float* scales,
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, const float* dout, float* dfmap1, float* const* dfmap2_levels,
-                            void* workspace, int64_t workspace_bytes, void* stream)
+                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream)
 {
     int rc = check_dims("alt_lookup_bwd", B, H, W);
     if (rc) return rc;
@@ -378,7 +378,7 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
         if (!tiles2_levels[l] || !dfmap2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: level %d pointer is null", l);
     }
     return launch_alt_lookup_bwd16(tiles1, tiles2_levels, scales, B, H, W, C, num_levels, radius, coords, dout, dfmap1,
-                                   dfmap2_levels, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
+                                   dfmap2_levels, accumulate, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
                                    (hipStream_t)stream);
 }
 

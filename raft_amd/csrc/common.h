@@ -51,7 +51,7 @@ size_t alt_tiles_bytes(int B, int C, int H, int W);
 int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
 size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r);
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
-                            int r, const float* coords, const float* dout, float* df1, float* const* df2,
+                            int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
                             void* workspace, size_t workspace_bytes, hipStream_t s);
 
 // floor + fraction of a sampling coordinate, memory-safe for NaN / huge values: anything

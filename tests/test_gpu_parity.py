@@ -651,6 +651,43 @@ def test_on_the_fly_backward_is_bit_reproducible(dev):
     assert np.isfinite(grads[0][0]).all() and np.abs(grads[0][1]).max() > 0
 
 
+def test_on_the_fly_gradients_sum_in_place(dev):
+    """The lookups of one AlternateCorrBlock add their feature gradients into shared sums inside the backward
+    kernel (accumulate = 1) instead of handing autograd one dense gradient per lookup.  Same bits as the sum of the
+    gradients of single-lookup blocks (a float addition either way); a second pass over a retained graph starts from
+    new sums; a pass that reaches only one of the lookups carries nothing over from another."""
+    from raft_amd import AlternateCorrBlock
+    rs = np.random.RandomState(11)
+    B, D, H, W, L, r = 2, 72, 30, 41, 3, 4
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].astype(np.float32)
+    cons = [_t(base + s * rs.randn(B, 2, H, W).astype(np.float32), dev) for s in (0.5, 2.0, 5.0)]
+    gouts = [_t(rs.randn(B, L * 81, H, W).astype(np.float32), dev) for _ in cons]
+
+    singles = []
+    for c, g in zip(cons, gouts):
+        f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+        AlternateCorrBlock(f1, f2, num_levels=L, radius=r)(c).backward(g)
+        singles.append((f1.grad.clone(), f2.grad.clone()))
+
+    f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+    blk = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)
+    outs = [blk(c) for c in cons]
+    torch.autograd.backward(outs, gouts, retain_graph=True)
+    # the engine runs the lookups' backward passes last lookup first
+    want1 = (singles[2][0] + singles[1][0]) + singles[0][0]
+    assert torch.equal(f1.grad, want1)
+    assert rel_err(f2.grad.cpu().numpy(), (singles[0][1] + singles[1][1] + singles[2][1]).cpu().numpy()) <= 1e-6
+    g1, g2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    torch.autograd.backward(outs, gouts, retain_graph=True)                       # second pass: same sums, not doubled
+    assert torch.equal(f1.grad, g1) and torch.equal(f2.grad, g2)
+    f1.grad = f2.grad = None
+    outs[1].backward(gouts[1])                                                    # one lookup only
+    assert torch.equal(f1.grad, singles[1][0]) and torch.equal(f2.grad, singles[1][1])
+
+
 def test_host_errors(dev):
     from raft_amd import CorrBlock
     f = torch.zeros(1, 8, 6, 6, device=dev)
