@@ -257,6 +257,27 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
                             float* dfmap1, float* const* dfmap2_levels, int accumulate,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Set-up and tear-down of one frame pair of the on-the-fly block, one host call each (what core/corr.py:64-73 does in
+ * its constructor -- the avg_pool2d chain -- plus the packed copies the kernels above read; and its adjoint).
+ *   raftcorr_alt_prepare       = raftcorr_alt_scales + the fmap2 pyramid (avg_pool2d(., 2, stride=2) chain, levels
+ *                         1 .. L-1; same summation order as torch's kernel) + raftcorr_alt_pack of fmap1 and of every
+ *                         level (+ raftcorr_alt_pack_tiles of the same maps when tiles1 / tiles2_levels are not NULL:
+ *                         needed for raftcorr_alt_lookup_bwd only).  packed2_levels / tiles2_levels: HOST arrays of L
+ *                         DEVICE buffers of raftcorr_alt_packed_bytes / raftcorr_alt_tiles_bytes(B, C, H>>l, W>>l) bytes;
+ *                         workspace: raftcorr_alt_prepare_workspace_bytes(...) bytes, 256-byte aligned (receives the
+ *                         pooled float32 levels; don't-care afterwards).
+ *   raftcorr_alt_features_bwd  d1 (B,H,W,C), d2_levels[l] (B,H>>l,W>>l,C): the NHWC gradients raftcorr_alt_lookup_bwd
+ *                         produces (summed over the lookups of the pair) -> dfmap1, dfmap2 (B,C,H,W) NCHW, fully
+ *                         overwritten: dfmap2 = level 0 + the pooled levels passed down the chain as avg_pool2d's
+ *                         backward does (t_l = d2_l + t_(l+1) / 4; cells the pooling dropped get nothing). */
+int64_t raftcorr_alt_prepare_workspace_bytes(int B, int C, int H, int W, int num_levels);
+int raftcorr_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int H, int W, int num_levels,
+                         float* scales, void* packed1, void* const* packed2_levels,
+                         void* tiles1, void* const* tiles2_levels,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+int raftcorr_alt_features_bwd(const float* d1, const float* const* d2_levels, int B, int C, int H, int W, int num_levels,
+                              float* dfmap1, float* dfmap2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

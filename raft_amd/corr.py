@@ -542,25 +542,32 @@ class _AltGradState:
 
 
 class _AltFeatures(torch.autograd.Function):
-    """fmap1 and the fmap2 levels -> anchor.  Like _BuildPyramid's anchor: a 1-element tensor that every lookup of the
-    block takes as an input.  The lookups' backward passes add their feature gradients into the block's accumulators
-    in place (raftcorr_alt_lookup_bwd with accumulate = 1: one kernel, no separate additions, no dense gradient per
-    lookup handed to autograd) and this node, which runs after all of them, hands the sums over."""
+    """fmap1, fmap2 -> anchor.  Like _BuildPyramid's anchor: a 1-element tensor that every lookup of the block takes
+    as an input.  The lookups' backward passes add their feature gradients into the block's sums in place
+    (raftcorr_alt_lookup_bwd with accumulate = 1: no dense gradient per lookup handed to autograd, no separate
+    additions) and this node, which runs after all of them, turns the sums into the gradients of the two maps
+    (raftcorr_alt_features_bwd: NHWC -> NCHW, pooled levels folded through the avg_pool2d chain of corr.py:69-73)."""
 
     @staticmethod
-    def forward(ctx, state, fmap1, *fmap2_levels):
+    def forward(ctx, state, fmap1, fmap2):
         ctx.state = state
-        ctx.shapes = [tuple(fmap1.shape)] + [tuple(t.shape) for t in fmap2_levels]
         ctx.set_materialize_grads(False)
         return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, danchor):
-        acc = ctx.state.take()
+        st = ctx.state
+        acc = st.take()
         if acc is None:                                         # no lookup of this backward pass reached the features
-            return (None,) * (1 + len(ctx.shapes))
-        return (None, *[t.permute(0, 3, 1, 2) for t in acc])    # NHWC sums, handed over as NCHW views
+            return None, None, None
+        B, C, H, W = st.shape
+        d1 = torch.empty(B, C, H, W, dtype=torch.float32, device=st.device)
+        d2 = torch.empty(B, C, H, W, dtype=torch.float32, device=st.device)
+        with _guard(d1):
+            _lib.check(_lib.load().raftcorr_alt_features_bwd(acc[0].data_ptr(), _lib.ptr_array(acc[1:]), B, C, H, W, st.L,
+                                                             d1.data_ptr(), d2.data_ptr(), _stream(d1)), "alt_features_bwd")
+        return None, d1, d2
 
 
 class _AltLookup(torch.autograd.Function):
@@ -621,51 +628,56 @@ class AlternateCorrBlock:
         B, C, H, W = fmap1.shape
         if (H >> (num_levels - 1)) < 1 or (W >> (num_levels - 1)) < 1:
             raise RuntimeError(f"AlternateCorrBlock: a {H} x {W} map has no level {num_levels - 1}: output size is too small")
-        self.pyramid = [(fmap1, fmap2)]                        # core/corr.py:69-73 (L+1 entries)
-        for _ in range(self.num_levels):
-            fmap1 = F.avg_pool2d(fmap1, 2, stride=2) if min(fmap1.shape[-2:]) >= 2 else fmap1[..., :0, :0]
-            fmap2 = F.avg_pool2d(fmap2, 2, stride=2) if min(fmap2.shape[-2:]) >= 2 else fmap2[..., :0, :0]
-            self.pyramid.append((fmap1, fmap2))
+        self._fmaps = (fmap1, fmap2)
+        self._pyramid = None                                    # core/corr.py:69-73, built when somebody asks for it
         self._shape = (B, C, H, W)
         lib = _lib.load()
-        f1 = self.pyramid[0][0].detach().contiguous()
-        f2 = [self.pyramid[i][1].detach().contiguous() for i in range(num_levels)]
+        f1, f2 = fmap1.detach().contiguous(), fmap2.detach().contiguous()
         dev = f1.device
-        self._scales = torch.empty(256, dtype=torch.float32, device=dev)      # partial maxima of |fmap1|, |fmap2|
-        with _guard(f1):
-            st = _stream(f1)
-            _lib.check(lib.raftcorr_alt_scales(f1.data_ptr(), f2[0].data_ptr(), B, C, H, W, self._scales.data_ptr(), st),
-                       "alt_scales")
-
-            def pack(t, scale_ptr):
-                b, c, h, w = t.shape
-                nbytes = lib.raftcorr_alt_packed_bytes(b, c, h, w)
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _lib.check(lib.raftcorr_alt_pack(t.data_ptr(), b, c, h, w, scale_ptr, buf.data_ptr(), nbytes, st), "alt_pack")
-                return buf
-
-            self._p1 = pack(f1, self._scales.data_ptr())
-            self._p2 = [pack(t, self._scales.data_ptr() + 128 * 4) for t in f2]
+        self._grad = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
+        # one buffer for the ranges, every packed copy (fmap1 and the L pyramid levels of fmap2; tile-major copies for the
+        # backward pass only when a gradient can flow to the features) and the set-up's workspace; one library call
+        dims = [(H, W)] + [(H >> l, W >> l) for l in range(num_levels)]
+        sizes = [1024] + [lib.raftcorr_alt_packed_bytes(B, C, h, w) for h, w in dims]
+        if self._grad:
+            sizes += [lib.raftcorr_alt_tiles_bytes(B, C, h, w) for h, w in dims]
+        sizes.append(lib.raftcorr_alt_prepare_workspace_bytes(B, C, H, W, num_levels))
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 255) // 256 * 256)
+        self._store = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
+        parts = [self._store[o:o + n] for o, n in zip(offs, sizes)]
+        n = 1 + num_levels
+        self._scales = parts[0].view(torch.float32)             # partial maxima of |fmap1|, |fmap2|
+        self._p1, self._p2 = parts[1], parts[2:1 + n]
         self._p2ptrs = _lib.ptr_array(self._p2)
-        self._grad = torch.is_grad_enabled() and (self.pyramid[0][0].requires_grad or self.pyramid[0][1].requires_grad)
         self._t1 = self._t2 = self._t2ptrs = self._anchor = None    # tile-major packed copies, for the backward pass only
         if self._grad:
-            with _guard(f1):
-                def pack_tiles(t, scale_ptr):
-                    b, c, h, w = t.shape
-                    nbytes = lib.raftcorr_alt_tiles_bytes(b, c, h, w)
-                    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    _lib.check(lib.raftcorr_alt_pack_tiles(t.data_ptr(), b, c, h, w, scale_ptr, buf.data_ptr(), nbytes, st),
-                               "alt_pack_tiles")
-                    return buf
-
-                self._t1 = pack_tiles(f1, self._scales.data_ptr())
-                self._t2 = [pack_tiles(t, self._scales.data_ptr() + 128 * 4) for t in f2]
+            self._t1, self._t2 = parts[1 + n], parts[2 + n:1 + 2 * n]
             self._t2ptrs = _lib.ptr_array(self._t2)
+        work = parts[-1]
+        with _guard(f1):
+            _lib.check(lib.raftcorr_alt_prepare(f1.data_ptr(), f2.data_ptr(), B, C, H, W, num_levels, self._scales.data_ptr(),
+                                                self._p1.data_ptr(), self._p2ptrs,
+                                                self._t1.data_ptr() if self._grad else None, self._t2ptrs,
+                                                work.data_ptr(), work.numel(), _stream(f1)), "alt_prepare")
+        if self._grad:
             self._gstate = _AltGradState(self._shape, num_levels, dev)
-            self._anchor = _AltFeatures.apply(self._gstate, self.pyramid[0][0],
-                                              *[self.pyramid[i][1] for i in range(num_levels)])
+            self._anchor = _AltFeatures.apply(self._gstate, fmap1, fmap2)
         self._work = None                                       # workspace of the backward kernels, shared by the lookups
+
+    @property
+    def pyramid(self):
+        """core/corr.py:69-73: [(fmap1, fmap2)] + num_levels pooled pairs (differentiable stock ops).  The kernels do not
+        read it -- raftcorr_alt_prepare pools fmap2 itself, with the same arithmetic -- so it is built on demand."""
+        if self._pyramid is None:
+            fmap1, fmap2 = self._fmaps
+            self._pyramid = [(fmap1, fmap2)]
+            for _ in range(self.num_levels):
+                fmap1 = F.avg_pool2d(fmap1, 2, stride=2) if min(fmap1.shape[-2:]) >= 2 else fmap1[..., :0, :0]
+                fmap2 = F.avg_pool2d(fmap2, 2, stride=2) if min(fmap2.shape[-2:]) >= 2 else fmap2[..., :0, :0]
+                self._pyramid.append((fmap1, fmap2))
+        return self._pyramid
 
     def _bwd_workspace(self):
         if self._work is None:

@@ -382,4 +382,48 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
                                    (hipStream_t)stream);
 }
 
+int64_t raftcorr_alt_prepare_workspace_bytes(int B, int C, int H, int W, int num_levels)
+{
+    if (B < 1 || C < 1 || H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS) return 0;
+    return (int64_t)alt_prepare_workspace_bytes(B, C, H, W, num_levels);
+}
+
+int raftcorr_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int H, int W, int num_levels,
+                         float* scales, void* packed1, void* const* packed2_levels,
+                         void* tiles1, void* const* tiles2_levels,
+                         void* workspace, int64_t workspace_bytes, void* stream)
+{
+    int rc = check_dims("alt_prepare", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !scales || !packed1 || !packed2_levels || C < 1)
+        return fail(RAFTCORR_EINVAL, "alt_prepare: bad argument");
+    if ((tiles1 == nullptr) != (tiles2_levels == nullptr))
+        return fail(RAFTCORR_EINVAL, "alt_prepare: tiles1 and tiles2_levels go together");
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_prepare: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1) return fail(RAFTCORR_EINVAL, "alt_prepare: level %d of a %d x %d map is empty", l, H, W);
+        if (!packed2_levels[l] || (tiles2_levels && !tiles2_levels[l]))
+            return fail(RAFTCORR_EINVAL, "alt_prepare: level %d pointer is null", l);
+    }
+    return launch_alt_prepare(fmap1, fmap2, B, C, H, W, num_levels, scales, packed1, packed2_levels, tiles1, tiles2_levels,
+                              workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
+}
+
+int raftcorr_alt_features_bwd(const float* d1, const float* const* d2_levels, int B, int C, int H, int W, int num_levels,
+                              float* dfmap1, float* dfmap2, void* stream)
+{
+    int rc = check_dims("alt_features_bwd", B, H, W);
+    if (rc) return rc;
+    if (!d1 || !d2_levels || !dfmap1 || !dfmap2 || C < 1) return fail(RAFTCORR_EINVAL, "alt_features_bwd: bad argument");
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_features_bwd: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1)
+            return fail(RAFTCORR_EINVAL, "alt_features_bwd: level %d of a %d x %d map is empty", l, H, W);
+        if (!d2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_features_bwd: level %d pointer is null", l);
+    }
+    return launch_alt_features_bwd(d1, d2_levels, B, C, H, W, num_levels, dfmap1, dfmap2, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -688,6 +688,56 @@ def test_on_the_fly_gradients_sum_in_place(dev):
     assert torch.equal(f1.grad, singles[1][0]) and torch.equal(f2.grad, singles[1][1])
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 47, 78, 4), (1, 7, 9, 10, 2), (3, 96, 32, 64, 4), (1, 33, 8, 8, 4), (1, 16, 21, 13, 1)])
+def test_on_the_fly_prepare_and_features_backward(shape, dev):
+    """raftcorr_alt_prepare (ranges + fmap2 pyramid + every packed copy in one call) against the separate calls on
+    torch's avg_pool2d chain (core/corr.py:69-73): identical bytes.  raftcorr_alt_features_bwd (NHWC sums -> NCHW
+    gradients, pooled levels folded) against autograd through that chain.  Odd sizes drop the last row / column."""
+    import ctypes
+    import torch.nn.functional as F
+    from raft_amd import AlternateCorrBlock, _lib
+    lib = _lib.load()
+    B, C, H, W, L = shape
+    rs = np.random.RandomState(B + C + H + W)
+    f1 = _t(rs.randn(B, C, H, W).astype(np.float32), dev, True)
+    f2 = _t((3.0 * rs.randn(B, C, H, W)).astype(np.float32), dev, True)
+    blk = AlternateCorrBlock(f1, f2, num_levels=L, radius=3)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    levels = [f2.detach()]
+    for _ in range(L - 1):
+        levels.append(F.avg_pool2d(levels[-1], 2, stride=2))
+    assert len(blk.pyramid) == L + 1 and torch.equal(blk.pyramid[L - 1][1], levels[L - 1])
+
+    def packed(fn, size_fn, t, scale_ptr):
+        b, c, h, w = t.shape
+        buf = torch.empty(size_fn(b, c, h, w), dtype=torch.uint8, device=dev)
+        _lib.check(fn(t.contiguous().data_ptr(), b, c, h, w, scale_ptr, buf.data_ptr(), buf.numel(), st), "pack")
+        return buf
+
+    sc = torch.empty(256, dtype=torch.float32, device=dev)
+    _lib.check(lib.raftcorr_alt_scales(f1.data_ptr(), f2.data_ptr(), B, C, H, W, sc.data_ptr(), st), "alt_scales")
+    assert torch.equal(sc, blk._scales)
+    assert torch.equal(packed(lib.raftcorr_alt_pack, lib.raftcorr_alt_packed_bytes, f1.detach(), sc.data_ptr()), blk._p1)
+    assert torch.equal(packed(lib.raftcorr_alt_pack_tiles, lib.raftcorr_alt_tiles_bytes, f1.detach(), sc.data_ptr()), blk._t1)
+    for l, t in enumerate(levels):
+        assert torch.equal(packed(lib.raftcorr_alt_pack, lib.raftcorr_alt_packed_bytes, t, sc.data_ptr() + 512), blk._p2[l]), l
+        assert torch.equal(packed(lib.raftcorr_alt_pack_tiles, lib.raftcorr_alt_tiles_bytes, t, sc.data_ptr() + 512), blk._t2[l]), l
+
+    d1 = _t(rs.randn(B, H, W, C).astype(np.float32), dev)
+    d2 = [_t(rs.randn(B, H >> l, W >> l, C).astype(np.float32), dev) for l in range(L)]
+    g1 = torch.full((B, C, H, W), float("nan"), device=dev)
+    g2 = torch.full((B, C, H, W), float("nan"), device=dev)
+    _lib.check(lib.raftcorr_alt_features_bwd(d1.data_ptr(), _lib.ptr_array(d2), B, C, H, W, L, g1.data_ptr(), g2.data_ptr(), st),
+               "alt_features_bwd")
+    x = f2.detach().clone().requires_grad_(True)
+    chain = [x]
+    for _ in range(L - 1):
+        chain.append(F.avg_pool2d(chain[-1], 2, stride=2))
+    torch.autograd.backward(chain, [t.permute(0, 3, 1, 2) for t in d2])
+    assert torch.equal(g1, d1.permute(0, 3, 1, 2))
+    assert rel_err(g2.cpu().numpy(), x.grad.cpu().numpy()) <= 1e-6
+
+
 def test_host_errors(dev):
     from raft_amd import CorrBlock
     f = torch.zeros(1, 8, 6, 6, device=dev)
