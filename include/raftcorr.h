@@ -229,6 +229,17 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
                             int B, int H, int W, int C, int num_levels, int radius,
                             const float* coords, float* out, void* stream);
 
+/* raftcorr_alt_lookup_fwd with the query tiles formed by WINDOW position instead of pixel position: same arguments,
+ * same results bit for bit (a query's outputs do not depend on which queries share its tile), one more small launch.
+ * A pixel tile's cost grows with the disagreement of its 64 flow vectors (the product covers the bounding box of their
+ * windows); tiles of queries whose window centres share an 8x8 target cell cost the same for any flow field.
+ * workspace: raftcorr_alt_lookup_fwd_sorted_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care. */
+int64_t raftcorr_alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int num_levels);
+int raftcorr_alt_lookup_fwd_sorted(const void* packed1, const void* const* packed2_levels, const float* scales,
+                                   int B, int H, int W, int C, int num_levels, int radius,
+                                   const float* coords, float* out,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Backward of raftcorr_alt_lookup_fwd w.r.t. the features, all levels (the reference exports corr_backward,
  * correlation.cpp:36-48 -> correlation_kernel.cu:123-256, but never wires it into autograd; per level this is that
  * kernel's arithmetic: g = bilinear-weighted sum of <= 4 d(out) cells per tap, d(fmap1) += g * fmap2,

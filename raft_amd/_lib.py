@@ -59,6 +59,9 @@ _SIGNATURES = {
     "raftcorr_alt_pack": ([_c_fp] + [_c_int] * 4 + [_c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_fwd": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
                                 [_c_fp, _c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_alt_lookup_fwd_sorted_workspace_bytes": ([_c_int] * 4, ctypes.c_int64),
+    "raftcorr_alt_lookup_fwd_sorted": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
+                                       [_c_fp, _c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_tiles_bytes": ([_c_int] * 4, ctypes.c_int64),
     "raftcorr_alt_pack_tiles": ([_c_fp] + [_c_int] * 4 + [_c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_bwd_workspace_bytes": ([_c_int] * 6, ctypes.c_int64),

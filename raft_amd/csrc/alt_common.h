@@ -53,19 +53,21 @@ struct Tile16 {
 
 // window origins of the tile's queries at level t.l + the bounding box of their in-level parts (wave 0: one lane
 // per query).  t.b, t.l, t.ty0, t.tx0 must be set; contains a barrier (every thread of the workgroup calls it).
+// qsrc: nullptr = the 8x8 pixel tile at (t.ty0, t.tx0); else 64 query pixel indices (-1 = empty slot).
 template <class Args>
-__device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile16& t)
+__device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile16& t, const int* __restrict__ qsrc = nullptr)
 {
     t.Hl = p.hl[t.l]; t.Wl = p.wl[t.l]; t.HWl = t.Hl * t.Wl;
     const int tid = threadIdx.x;
     if (tid < 64) {
         const int qi = tid, gy = t.ty0 + (qi >> 3), gx = t.tx0 + (qi & 7);
-        const bool valid = gy < p.H && gx < p.W;
+        const int pix = qsrc ? qsrc[qi] : ((gy < p.H && gx < p.W) ? gy * p.W + gx : -1);
+        const bool valid = pix >= 0;
         const int T = 2 * p.r + 2;
         int wx0 = -(1 << 24), wy0 = -(1 << 24);
         float fx = 0.f, fy = 0.f;
         if (valid) {
-            const size_t P = (size_t)p.H * p.W, q = (size_t)gy * p.W + gx;
+            const size_t P = (size_t)p.H * p.W, q = (size_t)pix;
             const float* c = p.coords + (size_t)t.b * 2 * P + q;
             const float s = 1.0f / (float)(1 << t.l);        // exact power of two == coords / 2**l (corr.py:86)
             int x0, y0;
@@ -84,7 +86,7 @@ __device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile1
             mny = min(mny, __shfl_xor(mny, m)); mxy = max(mxy, __shfl_xor(mxy, m));
         }
         sh.wx0[qi] = wx0; sh.wy0[qi] = wy0; sh.fx[qi] = fx; sh.fy[qi] = fy;
-        sh.qpix[qi] = valid ? gy * p.W + gx : -1;
+        sh.qpix[qi] = pix;
         if (tid == 0) { sh.box[0] = mnx; sh.box[1] = mxx; sh.box[2] = mny; sh.box[3] = mxy; }
     }
     __syncthreads();

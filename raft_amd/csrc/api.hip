@@ -334,7 +334,33 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
         if (!packed2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd: level %d pointer is null", l);
     }
     return launch_alt_lookup_fwd16(packed1, packed2_levels, scales, B, H, W, C, num_levels, radius, coords, out,
-                                   (hipStream_t)stream);
+                                   nullptr, 0, (hipStream_t)stream);
+}
+
+int64_t raftcorr_alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int num_levels)
+{
+    if (B < 1 || H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS) return 0;
+    return (int64_t)alt_lookup_fwd_sorted_workspace_bytes(B, H, W, num_levels);
+}
+
+int raftcorr_alt_lookup_fwd_sorted(const void* packed1, const void* const* packed2_levels, const float* scales,
+                                   int B, int H, int W, int C, int num_levels, int radius, const float* coords, float* out,
+                                   void* workspace, int64_t workspace_bytes, void* stream)
+{
+    int rc = check_dims("alt_lookup_fwd_sorted", B, H, W);
+    if (rc) return rc;
+    if (!packed1 || !packed2_levels || !scales || !coords || !out || !workspace)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: null pointer");
+    if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: C=%d radius=%d", C, radius);
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1)
+            return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: level %d of a %d x %d map is empty", l, H, W);
+        if (!packed2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: level %d pointer is null", l);
+    }
+    return launch_alt_lookup_fwd16(packed1, packed2_levels, scales, B, H, W, C, num_levels, radius, coords, out,
+                                   workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
 int64_t raftcorr_alt_tiles_bytes(int B, int C, int H, int W)

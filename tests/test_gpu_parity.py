@@ -507,7 +507,8 @@ def test_alternate_corr_block_matches_canonical_reference(name, dev):
                                   # B * query tiles >= 256: the backward runs 256-channel groups; 40 channels leave the
                                   # second slice empty, 136 leave it 8 channels (+ padding), 300 need a second group
                                   (4, 40, 60, 64, 3, 5, "wild"), (5, 136, 52, 60, 2, 3, "smooth"), (8, 300, 41, 47, 2, 4, "smooth")])
-def test_alternate_corr_block_edge_cases(case, dev):
+@pytest.mark.parametrize("tiles", ["pixel", "window"])
+def test_alternate_corr_block_edge_cases(case, tiles, dev):
     """Tile kernels of the on-the-fly path against the oracle's canonical CorrBlock (fwd + bwd):
     channel counts that are not a multiple of the staged chunk, ragged query tiles, incoherent
     flow (bounding boxes of many chunks), windows partly / entirely outside the map, radius > 4."""
@@ -540,7 +541,7 @@ def test_alternate_corr_block_edge_cases(case, dev):
     # non-finite / absurd coordinates are defined here as "far outside" (all taps zero); the
     # oracle gets the same thing spelled as a finite far-away coordinate
     con_ref = np.where(np.isfinite(con) & (np.abs(con) < 1e6), con, -1e5).astype(np.float32)
-    o, g1, g2 = run(lambda a, b: AlternateCorrBlock(a, b, num_levels=L, radius=r), dev, con)
+    o, g1, g2 = run(lambda a, b: AlternateCorrBlock(a, b, num_levels=L, radius=r, tiles=tiles), dev, con)
     ro, r1, r2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu", con_ref)
     assert o.shape == ro.shape
     assert rel_err(o, ro) <= TOL
@@ -736,6 +737,40 @@ def test_on_the_fly_prepare_and_features_backward(shape, dev):
     torch.autograd.backward(chain, [t.permute(0, 3, 1, 2) for t in d2])
     assert torch.equal(g1, d1.permute(0, 3, 1, 2))
     assert rel_err(g2.cpu().numpy(), x.grad.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 47, 156), (2, 64, 136, 240), (6, 32, 50, 90), (1, 24, 3, 2050)])
+def test_on_the_fly_window_tiles(shape, dev):
+    """tiles="window" (raftcorr_alt_lookup_fwd_sorted: query tiles by window position) against tiles="pixel": same
+    samples up to the last bit of a sum (a window split over two passes of a box adds its halves in another order),
+    for smooth flow, per-pixel noise, coordinates far outside the map and non-finite ones; every output element
+    written (the output starts as NaN inside torch.empty's storage only by accident, so it is checked for finiteness);
+    more than one segment of 8192 queries at the larger shapes."""
+    from raft_amd import AlternateCorrBlock
+    B, D, H, W = shape
+    rs = np.random.RandomState(H + W)
+    f1, f2 = _t(rs.randn(B, D, H, W).astype(np.float32), dev), _t(rs.randn(B, D, H, W).astype(np.float32), dev)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].astype(np.float32)
+    L = 4 if min(H, W) >= 8 else 2
+    with torch.no_grad():
+        pix = AlternateCorrBlock(f1, f2, num_levels=L, radius=4)
+        win = AlternateCorrBlock(f1, f2, num_levels=L, radius=4, tiles="window")
+        for kind in ("identity", "shift", "noise", "wild"):
+            if kind == "identity":
+                con = np.repeat(base, B, 0)
+            elif kind == "shift":
+                con = base + rs.uniform(-20, 20, (B, 2, 1, 1)).astype(np.float32)
+            elif kind == "noise":
+                con = base + 5.0 * rs.randn(B, 2, H, W).astype(np.float32)
+            else:
+                con = (rs.rand(B, 2, H, W) * [[[W + 40]], [[H + 40]]] - 20).astype(np.float32)
+                con[0, :, 0, 0] = [np.inf, 1.0]
+                con[0, :, H - 1, W - 1] = [-1e9, np.nan]
+            c = _t(np.ascontiguousarray(con, dtype=np.float32), dev)
+            a, b = pix(c), win(c)
+            assert torch.isfinite(b).all(), kind
+            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 1e-6, kind
 
 
 def test_host_errors(dev):
