@@ -235,6 +235,7 @@ class Bf16AllPairs(SintelFwd):
 
 class KittiAlt(Workload):
     needs_grad = True
+    tiles = "window"            # the config's coordinates are per-pixel random walks: query tiles by window position
 
     def __init__(self, *a):
         super().__init__(*a)
@@ -247,7 +248,7 @@ class KittiAlt(Workload):
         self.f2.grad = None
         if ev:
             ev[0].record()
-        blk = AlternateCorrBlock(self.f1, self.f2, num_levels=LEVELS, radius=RADIUS)
+        blk = AlternateCorrBlock(self.f1, self.f2, num_levels=LEVELS, radius=RADIUS, tiles=self.tiles)
         outs = [blk(c) for c in self.coords]
         if ev:
             ev[1].record()
@@ -428,6 +429,8 @@ def extras_kitti(torch, wl, dev):
         work = torch.empty(wb, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         o = torch.empty(B, LEVELS * 81, H, W, device=dev)
+        swb = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, LEVELS)
+        swork = torch.empty(swb, dtype=torch.uint8, device=dev)
         for tag, c in (("identity", wl.coords[0]), ("sigma3", wl.coords[1]), ("sigma6", wl.coords[4])):
             tf = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(),
                                                                       B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
@@ -435,6 +438,11 @@ def extras_kitti(torch, wl, dev):
             tb = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(gblk._t1.data_ptr(), gblk._t2ptrs, gblk._scales.data_ptr(),
                                                                       B, H, W, D, LEVELS, RADIUS, c.data_ptr(), gout.data_ptr(),
                                                                       d1.data_ptr(), dlv, 0, work.data_ptr(), wb, stream))
+            ts = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd_sorted(
+                blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
+                swork.data_ptr(), swb, stream))
+            out["alt_fwd_window_tiles_" + tag] = frac_entry("alt_bucket_kernel + alt_fwd16_kernel", ts, "mfma", w["alt_flops"],
+                                                            MFMA_F32_PEAK_TFLOPS, "TFLOP/s", compulsory_bytes=w["alt_bytes"])
             out["alt_fwd_" + tag] = frac_entry("alt_fwd16_kernel", tf, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
                                                "TFLOP/s", hbm_GBs=w["alt_bytes"] / tf / 1e3,
                                                hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS,
@@ -443,6 +451,21 @@ def extras_kitti(torch, wl, dev):
                                                MFMA_F32_PEAK_TFLOPS, "TFLOP/s", hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
                                                hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS,
                                                compulsory_bytes=w["alt_bwd_bytes"])
+    # the whole step with 8x8 pixel tiles in the forward pass (the default of AlternateCorrBlock: flow fields are smooth)
+    wl.tiles = "pixel"
+    try:
+        for _ in range(3):
+            wl.step(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            wl.step(None)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        out["step_pixel_tiles"] = {"frame_pairs_per_sec": B / ms * 1e3, "ms_per_step": ms, "steps": n}
+    finally:
+        wl.tiles = type(wl).tiles
     return out
 
 
@@ -739,7 +762,8 @@ def main():
     phases = [float(np.median([e[i].elapsed_time(e[i + 1]) for e in ev])) * 1e3 for i in range(wl.n_events - 1)]
     kernels, dom = wl.kernels(phases)
     what = {"sintel": f"fp32 all-pairs build + {LEVELS}-level pyramid + {iters}-iter canonical lookup fwd (r={RADIUS})",
-            "kitti_alt": f"AlternateCorrBlock (on-the-fly), {iters} lookups fwd + bwd (r={RADIUS}, {LEVELS} levels)",
+            "kitti_alt": f"AlternateCorrBlock (on-the-fly, forward query tiles by {KittiAlt.tiles}), {iters} lookups fwd + bwd "
+                         f"(r={RADIUS}, {LEVELS} levels)",
             "things_train": f"fp32 all-pairs build + {iters} lookups, fwd + bwd"
                             + (f" + all-reduce of {GRAD_BUCKET} fp32 (RCCL)" if world > 1 else ""),
             "1080p": f"bf16-operand MFMA all-pairs build (bf16 pyramid) + {iters}-iter lookup fwd"}[args.config]
