@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Experiment harness (not product code): on-the-fly forward with pixel tiles against window-sorted tiles.
-usage: alt_sort_lab.py [H W B]"""
+usage: alt_sort_lab.py [lib.so] [H W B]"""
 import os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from raft_amd import AlternateCorrBlock, _lib
+from raft_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
+    _lib.LIB_PATH = os.path.abspath(sys.argv.pop(1))
+from raft_amd import AlternateCorrBlock
 import bench
 H, W, B = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (47, 156, 1)
 D, L, R = 256, 4, 4
