@@ -75,12 +75,19 @@ void alt_features_bwd_kernel(FeatBwdArgs p)
                 t = p.d1[((size_t)b * HW + pix) * p.C + c];
             } else {
                 const int y = pix / p.W, x = pix - y * p.W;
-                for (int l = p.L - 1; l >= 0; --l) {
+                float v[RAFTCORR_MAX_LEVELS];                // all levels' loads first: they do not depend on each other
+#pragma unroll
+                for (int l = 0; l < RAFTCORR_MAX_LEVELS; ++l) {
+                    const int Hl = p.H >> l, Wl = p.W >> l, yl = y >> l, xl = x >> l;
+                    v[l] = (l < p.L && yl < Hl && xl < Wl) ? p.d2[l][(((size_t)b * Hl + yl) * Wl + xl) * p.C + c] : 0.f;
+                }
+#pragma unroll
+                for (int l = RAFTCORR_MAX_LEVELS - 1; l >= 0; --l) {
                     const int Hl = p.H >> l, Wl = p.W >> l, yl = y >> l, xl = x >> l;
                     // the running sum lives at level l + 1; it reaches this level-l cell only if the pooling kept the cell
-                    t = (((yl >> 1) < (Hl >> 1) && (xl >> 1) < (Wl >> 1)) ? t * 0.25f : 0.f);
-                    if (yl < Hl && xl < Wl) t += p.d2[l][(((size_t)b * Hl + yl) * Wl + xl) * p.C + c];
-                    else                    t = 0.f;
+                    // (a cell outside its level has v = 0 and no parent either: (yl >> 1) >= (Hl >> 1) then)
+                    t = ((yl >> 1) < (Hl >> 1) && (xl >> 1) < (Wl >> 1)) ? t * 0.25f : 0.f;
+                    t = (yl < Hl && xl < Wl) ? t + v[l] : 0.f;
                 }
             }
         }
