@@ -78,14 +78,19 @@ __device__ __forceinline__ int ttiles_of(const AltBwdArgs& p, int l) { return tt
 
 // ---------------------------------------------------------------------------------------------
 // tile-major pack: (B, C, Hm, Wm) fp32 NCHW -> [B][tile][Cp][hi 8 rows | lo 8 rows][8 px] fp16, scaled, zero padded.
-// grid (tiles, Cp / 32, B), block 256: thread = (row = tid & 7, channel = tid >> 3)
+// grid (sum over the maps of their tiles, Cp / 32, B), block 256: thread = (row = tid & 7, channel = tid >> 3)
 __global__ __launch_bounds__(256)
-void alt_pack_tiles_kernel(const float* __restrict__ f, uint4* __restrict__ packed, int C, int Cp, int Hm, int Wm,
-                           const float* __restrict__ maxpart)
+void alt_pack_tiles_kernel(PackSet ps)
 {
+    const int m = packset_map(ps, blockIdx.x);
+    const float* __restrict__ f = ps.src[m];
+    uint4* __restrict__ packed = ps.dst[m];
+    const float* __restrict__ maxpart = ps.maxpart[m];
+    const int C = ps.C, Cp = ps.Cp, Hm = ps.h[m], Wm = ps.w[m];
     const float scale = ldexpf(1.0f, range_exp16(wave_max128(fmaxf(maxpart[threadIdx.x & 63], maxpart[(threadIdx.x & 63) + 64]))));
     const int tx_n = (Wm + 7) >> 3;
-    const int tile = blockIdx.x, row = threadIdx.x & 7, c = blockIdx.y * 32 + (threadIdx.x >> 3), b = blockIdx.z;
+    const int tile = blockIdx.x - ps.blk0[m], ntiles = ps.blk0[m + 1] - ps.blk0[m];
+    const int row = threadIdx.x & 7, c = blockIdx.y * 32 + (threadIdx.x >> 3), b = blockIdx.z;
     const int y = (tile / tx_n) * 8 + row, x0 = (tile % tx_n) * 8;
     const bool live = c < C && y < Hm;
     const float* src = f + ((size_t)b * C + min(c, C - 1)) * Hm * Wm + (size_t)min(y, Hm - 1) * Wm;
@@ -101,7 +106,7 @@ void alt_pack_tiles_kernel(const float* __restrict__ f, uint4* __restrict__ pack
         h[0][j] = __builtin_bit_cast(unsigned short, hi);
         h[1][j] = __builtin_bit_cast(unsigned short, lo);
     }
-    uint4* dst = packed + (((size_t)b * gridDim.x + tile) * Cp + c) * 16 + row;
+    uint4* dst = packed + (((size_t)b * ntiles + tile) * Cp + c) * 16 + row;
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) {
         uint4 w;
@@ -597,11 +602,22 @@ size_t alt_tiles_bytes(int B, int C, int H, int W)
     return (size_t)B * ((W + 7) / 8) * ((H + 7) / 8) * Cp * 256;
 }
 
+int launch_alt_pack_tiles_set(const float* const* fmaps, const int* hs, const int* ws, const float* const* maxparts,
+                              void* const* packed, int n, int B, int C, hipStream_t s)
+{
+    PackSet ps = {};
+    ps.n = n; ps.C = C; ps.Cp = (C + 31) / 32 * 32;
+    for (int m = 0; m < n; ++m) {
+        ps.src[m] = fmaps[m]; ps.dst[m] = (uint4*)packed[m]; ps.maxpart[m] = maxparts[m]; ps.h[m] = hs[m]; ps.w[m] = ws[m];
+        ps.blk0[m + 1] = ps.blk0[m] + ((ws[m] + 7) / 8) * ((hs[m] + 7) / 8);
+    }
+    hipLaunchKernelGGL(alt_pack_tiles_kernel, dim3(ps.blk0[n], ps.Cp / 32, B), dim3(256), 0, s, ps);
+    return check_launch("alt_pack_tiles_kernel");
+}
+
 int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s)
 {
-    const int Cp = (C + 31) / 32 * 32, tiles = ((W + 7) / 8) * ((H + 7) / 8);
-    hipLaunchKernelGGL(alt_pack_tiles_kernel, dim3(tiles, Cp / 32, B), dim3(256), 0, s, fmap, (uint4*)packed, C, Cp, H, W, maxpart);
-    return check_launch("alt_pack_tiles_kernel");
+    return launch_alt_pack_tiles_set(&fmap, &H, &W, &maxpart, &packed, 1, B, C, s);
 }
 
 size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r)

@@ -36,6 +36,23 @@ __device__ __forceinline__ void glds16(const uint4* gsrc, uint4* lds_chunk)
                                      (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
 }
 
+// up to 1 + RAFTCORR_MAX_LEVELS maps of one batch packed by one launch (fmap1 and the fmap2 pyramid): blockIdx.x in
+// [blk0[m], blk0[m + 1]) works on map m
+struct PackSet {
+    const float* src[RAFTCORR_MAX_LEVELS + 1];
+    uint4* dst[RAFTCORR_MAX_LEVELS + 1];
+    const float* maxpart[RAFTCORR_MAX_LEVELS + 1];
+    int h[RAFTCORR_MAX_LEVELS + 1], w[RAFTCORR_MAX_LEVELS + 1], blk0[RAFTCORR_MAX_LEVELS + 2];
+    int n, C, Cp;
+};
+
+__device__ __forceinline__ int packset_map(const PackSet& ps, int bx)
+{
+    int m = 0;
+    while (m + 1 < ps.n && bx >= ps.blk0[m + 1]) ++m;
+    return m;
+}
+
 struct TileQ {
     int wx0[TQ], wy0[TQ];                         // window origin (x0 - r, y0 - r) per query
     float fx[TQ], fy[TQ];

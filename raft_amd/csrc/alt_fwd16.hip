@@ -59,12 +59,16 @@ struct TileSh : TileQ {
 };
 
 // ---------------------------------------------------------------------------------------------
-// pack: (B, C, HW) fp32 NCHW -> [B][HW][Cp/32][piece 2][32 ch] fp16, scaled.  grid (ceil(HW/256), Cp/8, B)
+// pack: (B, C, HW) fp32 NCHW -> [B][HW][Cp/32][piece 2][32 ch] fp16, scaled.  grid (sum over the maps of ceil(HW/256), Cp/8, B)
 __global__ __launch_bounds__(256)
-void alt_pack16_kernel(const float* __restrict__ f, uint4* __restrict__ packed, int C, int Cp, int HW,
-                       const float* __restrict__ maxpart)
+void alt_pack16_kernel(PackSet ps)
 {
-    const int pix = blockIdx.x * 256 + threadIdx.x, c0 = blockIdx.y * 8, b = blockIdx.z;
+    const int m = packset_map(ps, blockIdx.x);
+    const float* __restrict__ f = ps.src[m];
+    uint4* __restrict__ packed = ps.dst[m];
+    const float* __restrict__ maxpart = ps.maxpart[m];
+    const int C = ps.C, Cp = ps.Cp, HW = ps.h[m] * ps.w[m];
+    const int pix = (blockIdx.x - ps.blk0[m]) * 256 + threadIdx.x, c0 = blockIdx.y * 8, b = blockIdx.z;
     const float scale = ldexpf(1.0f, range_exp16(wave_max128(fmaxf(maxpart[threadIdx.x & 63], maxpart[(threadIdx.x & 63) + 64]))));
     if (pix >= HW) return;
     float x[8];
@@ -412,12 +416,22 @@ size_t alt_packed_bytes(int B, int C, int H, int W)
     return (size_t)B * H * W * Cp * 4;
 }
 
+int launch_alt_pack_set(const float* const* fmaps, const int* hs, const int* ws, const float* const* maxparts,
+                        void* const* packed, int n, int B, int C, hipStream_t s)
+{
+    PackSet ps = {};
+    ps.n = n; ps.C = C; ps.Cp = (C + 31) / 32 * 32;
+    for (int m = 0; m < n; ++m) {
+        ps.src[m] = fmaps[m]; ps.dst[m] = (uint4*)packed[m]; ps.maxpart[m] = maxparts[m]; ps.h[m] = hs[m]; ps.w[m] = ws[m];
+        ps.blk0[m + 1] = ps.blk0[m] + (hs[m] * ws[m] + 255) / 256;
+    }
+    hipLaunchKernelGGL(alt_pack16_kernel, dim3(ps.blk0[n], ps.Cp / 8, B), dim3(256), 0, s, ps);
+    return check_launch("alt_pack16_kernel");
+}
+
 int launch_alt_pack(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s)
 {
-    const int Cp = (C + 31) / 32 * 32, HW = H * W;
-    hipLaunchKernelGGL(alt_pack16_kernel, dim3((HW + 255) / 256, Cp / 8, B), dim3(256), 0, s, fmap, (uint4*)packed, C, Cp, HW,
-                       maxpart);
-    return check_launch("alt_pack16_kernel");
+    return launch_alt_pack_set(&fmap, &H, &W, &maxpart, &packed, 1, B, C, s);
 }
 
 namespace {

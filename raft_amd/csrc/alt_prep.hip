@@ -138,12 +138,19 @@ int launch_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int
         level[l] = next;
         next += ((size_t)total + 63) / 64 * 64;
     }
-    rc = launch_alt_pack(fmap1, B, C, H, W, scales, packed1, s);
-    for (int l = 0; l < L && !rc; ++l) rc = launch_alt_pack(level[l], B, C, H >> l, W >> l, scales + 128, packed2[l], s);
+    // fmap1 and the L levels of fmap2: one launch per packed format
+    const float* maps[RAFTCORR_MAX_LEVELS + 1] = {fmap1};
+    const float* mp[RAFTCORR_MAX_LEVELS + 1] = {scales};
+    void* dst[RAFTCORR_MAX_LEVELS + 1] = {packed1};
+    void* dstt[RAFTCORR_MAX_LEVELS + 1] = {tiles1};
+    int hs[RAFTCORR_MAX_LEVELS + 1] = {H}, ws[RAFTCORR_MAX_LEVELS + 1] = {W};
+    for (int l = 0; l < L; ++l) {
+        maps[l + 1] = level[l]; mp[l + 1] = scales + 128; dst[l + 1] = packed2[l]; hs[l + 1] = H >> l; ws[l + 1] = W >> l;
+        if (tiles1) dstt[l + 1] = tiles2[l];
+    }
+    rc = launch_alt_pack_set(maps, hs, ws, mp, dst, L + 1, B, C, s);
     if (rc || !tiles1) return rc;
-    rc = launch_alt_pack_tiles(fmap1, B, C, H, W, scales, tiles1, s);
-    for (int l = 0; l < L && !rc; ++l) rc = launch_alt_pack_tiles(level[l], B, C, H >> l, W >> l, scales + 128, tiles2[l], s);
-    return rc;
+    return launch_alt_pack_tiles_set(maps, hs, ws, mp, dstt, L + 1, B, C, s);
 }
 
 int launch_alt_features_bwd(const float* d1, const float* const* d2, int B, int C, int H, int W, int L,

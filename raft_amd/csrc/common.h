@@ -43,6 +43,10 @@ int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, 
                          int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
 int launch_maxabs(const float* f1, const float* f2, size_t n, float* out, hipStream_t s);
 size_t alt_packed_bytes(int B, int C, int H, int W);
+int launch_alt_pack_set(const float* const* fmaps, const int* hs, const int* ws, const float* const* maxparts,
+                        void* const* packed, int n, int B, int C, hipStream_t s);
+int launch_alt_pack_tiles_set(const float* const* fmaps, const int* hs, const int* ws, const float* const* maxparts,
+                              void* const* packed, int n, int B, int C, hipStream_t s);
 int launch_alt_pack(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
 int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
