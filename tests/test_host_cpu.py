@@ -77,6 +77,16 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.raftcorr_lookup_fwd(ptrs, 1, 55, 128, 4, 4, 8, 7, 8, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 0, 4, None) == -1
     assert lib.raftcorr_alt_forward(8, 8, 8, 8, 1, 1, 4, 4, 4, 4, 16, 8, None) == -2   # radius > 7
+    # the entry points of round 2: sizes are plain host arithmetic, bad arguments come back as errors
+    assert lib.raftcorr_alt_prepare_workspace_bytes(1, 256, 47, 156, 4) >= 4 * 256 * (23 * 78 + 11 * 39 + 5 * 19)
+    assert lib.raftcorr_alt_prepare_workspace_bytes(1, 256, 47, 156, 9) == 0
+    assert lib.raftcorr_alt_prepare(None, None, 1, 256, 47, 156, 4, None, None, None, None, None, None, 0, None) == -1
+    assert lib.raftcorr_alt_features_bwd(8, some, 1, 8, 6, 8, 4, 8, 8, None) == -1      # level 3 of a 6x8 map is empty
+    assert lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(1, 47, 156, 4) > 4 * 4 * 64 * ((47 * 156 + 63) // 64)
+    assert lib.raftcorr_alt_lookup_fwd_sorted(8, some, 8, 1, 47, 156, 256, 4, 4, 8, 8, None, 0, None) == -1
+    assert b"null" in lib.raftcorr_last_error()
+    assert lib.raftcorr_alt_lookup_bwd(8, some, 8, 1, 47, 156, 256, 4, 4, 8, 8, 8, some, 0, None, 0, None) == -1
+    assert b"workspace" in lib.raftcorr_last_error()
 
 
 def test_host_classes_validate_before_any_launch():
@@ -86,6 +96,8 @@ def test_host_classes_validate_before_any_launch():
         CorrBlock(f, f)
     with pytest.raises(RuntimeError, match="fmap1 must be a CUDA tensor"):
         AlternateCorrBlock(f, f)
+    with pytest.raises(RuntimeError, match="tiles must be"):
+        AlternateCorrBlock(f, f, tiles="sorted")
     with pytest.raises(RuntimeError, match="fmap1 must be a CUDA tensor"):
         alt_cuda_corr.forward(f, f, torch.zeros(1, 1, 6, 6, 2), 4)
 
