@@ -330,8 +330,8 @@ class CorrBlock:
 
     precision (keyword, not in the reference) selects the arithmetic of the forward contraction; the
     pyramid and the lookup are fp32 in every case, and the backward contractions run fp32-grade
-    (three bf16 pieces per operand, six products, fp32 accumulation; exact fp32 MFMA when the
-    operands are not 16-byte aligned) with a fixed summation order -- gradients are reproducible
+    (range-scaled operands split into two fp16 pieces, three products, fp32 accumulation; exact fp32
+    MFMA when the operands are not 16-byte aligned) with a fixed summation order -- gradients are reproducible
     bit for bit:
       "fp32"    (default) exact fp32 FMA chain on the fp32 matrix cores;
       "bf16x3"  operands split into three bfloat16 pieces, six bf16 MFMA products: fp32-grade

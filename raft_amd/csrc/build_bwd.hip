@@ -1,9 +1,13 @@
 // Backward of the pyramid build: pooled-level gradients are folded down to level 0, then two
 // contractions give the feature gradients.  Aligned operands (the normal case) run them on the
-// 16-bit matrix cores with every operand split into three bf16 pieces and six products
-// (gemm_bf16x3_kernel: fp32-grade); unaligned operands take the exact fp32-MFMA kernel
-// (gemm_f32_kernel).  Split-K partial products go to separate planes and are added in a fixed
-// order: the gradients are bit-reproducible.
+// 16-bit matrix cores at fp32-grade accuracy (gemm_bf16x3_kernel<., F16 = true>): both operands are
+// range-scaled by a power of two and split into two fp16 pieces while they are staged, three products
+// (hi*hi + hi*lo + lo*hi), exact unscale -- the fp16x2 scheme of build_pyramid.hip.  The ranges cost
+// almost nothing: max|F1|, max|F2| are one small pass, max|folded gradient| is taken by the fold kernel
+// on the values it writes anyway (per-workgroup maxima, reduced by corr_maxabs_kernel: no atomics).
+// The three-piece bf16 variant (six products, no ranges needed) remains as the F16 = false
+// instantiation; unaligned operands take the exact fp32-MFMA kernel (gemm_f32_kernel).  Split-K partial
+// products go to separate planes and are added in a fixed order: the gradients are bit-reproducible.
 //
 // Replaces what autograd runs behind core/corr.py:26,59,61 in the reference
 // (avg_pool2d_backward x (L-1), the scale, and the two GEMMs of bmm's backward):
@@ -29,7 +33,22 @@ struct FoldArgs {
     float scale;        // 1/sqrt(D)
     float sqrt_d;
     int exact;
+    float* wgmax;       // [gridDim.x] max |folded level 0| per workgroup (the range pass of the fp16x2 contractions), or nullptr
 };
+
+constexpr unsigned FOLD_MAX_GRID = 32768;
+
+// max |v| of the workgroup's values -> wgmax[blockIdx.x] (plain stores, reduced by corr_maxabs_kernel afterwards)
+__device__ __forceinline__ void fold_note_max(float* wgmax, float m)
+{
+    __shared__ float wm[4];
+    if (!wgmax) return;                                      // (uniform)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) wgmax[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
 
 __global__ __launch_bounds__(256)
 void corr_fold_levels_kernel(FoldArgs p)
@@ -38,6 +57,7 @@ void corr_fold_levels_kernel(FoldArgs p)
     // parents (layout.h): a 16-byte load, up to three scalar loads, a 16-byte store
     const size_t quads = p.BN * (size_t)(p.s0 >> 2);
     const int qps = (int)(p.s0 >> 2);                       // quads per slab
+    float vmax = 0.f;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < quads; e += (size_t)gridDim.x * 256) {
         const size_t qb = e / qps;
         const int c = (int)(e - qb * qps) << 2;
@@ -56,7 +76,9 @@ void corr_fold_levels_kernel(FoldArgs p)
         if (p.exact) { v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale; }
         else { v.x /= p.sqrt_d; v.y /= p.sqrt_d; v.z /= p.sqrt_d; v.w /= p.sqrt_d; }
         *(float4*)(p.d0 + qb * p.s0 + c) = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    fold_note_max(p.wgmax, vmax);
 }
 
 // the same, one cell per thread: for gradient buffers that are not 16-byte aligned
@@ -64,6 +86,7 @@ __global__ __launch_bounds__(256)
 void corr_fold_levels_scalar_kernel(FoldArgs p)
 {
     const size_t total = p.BN * (size_t)p.s0;
+    float vmax = 0.f;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t qb = e / p.s0;
         const int c = (int)(e - qb * p.s0);
@@ -76,9 +99,11 @@ void corr_fold_levels_scalar_kernel(FoldArgs p)
             const int ph = patch / p.PW, pwi = patch - ph * p.PW;
             g += 0.015625f * p.d3[qb * p.s3 + ((ph >> 1) * p.PW + pwi) * 4 + (n & 1) + (ph & 1) * 2];
         }
-        const float v = p.d0[e] + g;
-        p.d0[e] = p.exact ? v * p.scale : v / p.sqrt_d;
+        const float v = p.d0[e] + g, w = p.exact ? v * p.scale : v / p.sqrt_d;
+        p.d0[e] = w;
+        vmax = fmaxf(vmax, fabsf(w));
     }
+    fold_note_max(p.wgmax, vmax);
 }
 
 // levels >= 4 (row-major): fine += 0.25 * coarse[parent]
@@ -162,6 +187,8 @@ struct GemmArgs {
     float* P;            // ksplit > 1: partial products [ksplit][batch][M][ldc]
     int batch;
     int vecA, vecB;      // 16-byte loads legal (alignment + extents)
+    const float* maxA;   // fp16x2 kernel: [128] partial maxima of |A| and of |B| (range scaling)
+    const float* maxB;
 };
 
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
@@ -341,13 +368,50 @@ __device__ __forceinline__ void split3(const float (&x)[8], uint4 (&out)[3])
     }
 }
 
-template <bool B_K_CONTIG>
+// x * scale -> two fp16 pieces (hi = RNE, lo = the exact remainder rounded once): the fp16x2 scheme of
+// build_pyramid.hip / alt_fwd16.hip, 22 significand bits when the scale puts max|x| into [2^14, 2^15)
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2(const float (&x)[8], float scale, uint4 (&out)[3])
+{
+    unsigned short h[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = x[j] * scale;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        h[0][j] = __builtin_bit_cast(unsigned short, hi);
+        h[1][j] = __builtin_bit_cast(unsigned short, lo);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        out[c] = make_uint4(h[c][0] | ((unsigned)h[c][1] << 16), h[c][2] | ((unsigned)h[c][3] << 16),
+                            h[c][4] | ((unsigned)h[c][5] << 16), h[c][6] | ((unsigned)h[c][7] << 16));
+}
+
+// power-of-two factor that maps the maximum of 128 partial maxima into [2^14, 2^15) (as build_pyramid.hip:range_exponent)
+__device__ __forceinline__ int gemm_range_exp(const float* part)
+{
+    const int lane = threadIdx.x & 63;
+    float m = fmaxf(part[lane], part[lane + 64]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);
+    return 15 - e;
+}
+
+// F16 = false: three bf16 pieces per operand, six products (any finite input).  F16 = true: two fp16 pieces of the
+// range-scaled operands, three products (hi*hi + hi*lo + lo*hi), exact power-of-two unscale in the epilogue: half the
+// matrix-core work and two thirds of the conversion work; needs the operands' maxima (p.maxA, p.maxB).
+template <bool B_K_CONTIG, bool F16>
 __global__ __launch_bounds__(256, 2)
 void gemm_bf16x3_kernel(GemmArgs p)
 {
     constexpr int TM = 128, TN = 128, TK = 32;
+    constexpr int NP = F16 ? 2 : 3;                   // pieces per operand
     constexpr int PLANE = 128 + 2;                    // uint4 slots per k-group plane (2 slots = 32 B of padding)
-    constexpr int OPU = 3 * 4 * PLANE;                // uint4 slots per operand image
+    constexpr int OPU = NP * 4 * PLANE;               // uint4 slots per operand image
     __shared__ uint4 As[OPU];
     __shared__ uint4 Bs[OPU];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -363,6 +427,12 @@ void gemm_bf16x3_kernel(GemmArgs p)
     float* __restrict__ C = p.ksplit > 1 ? p.P + ((size_t)ks * p.batch + bz) * p.sC : p.C + bz * p.sC;
     auto desc = [](const float* base) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    };
+    const int eA = F16 ? gemm_range_exp(p.maxA) : 0, eB = F16 ? gemm_range_exp(p.maxB) : 0;
+    const float scA = ldexpf(1.0f, eA), scB = ldexpf(1.0f, eB), unscale = ldexpf(1.0f, -(eA + eB));
+    auto split = [](const float (&x)[8], float scale, uint4 (&out)[3]) {
+        if (F16) split2(x, scale, out);
+        else     split3(x, out);
     };
 
     // staging registers: K-contiguous operand: 2 slots x 8 k (two 16-byte loads each);
@@ -416,25 +486,25 @@ void gemm_bf16x3_kernel(GemmArgs p)
             const int kg = tid & 3;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                split3(xa[i], pc);
+                split(xa[i], scA, pc);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) As[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+                for (int c = 0; c < NP; ++c) As[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
             }
         }
         if (B_K_CONTIG) {
             const int kg = tid & 3;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                split3(xb[i], pc);
+                split(xb[i], scB, pc);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Bs[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+                for (int c = 0; c < NP; ++c) Bs[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                split3(xb[i], pc);
+                split(xb[i], scB, pc);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Bs[(c * 4 + (tid >> 7) + 2 * i) * PLANE + (tid & 127)] = pc[c];
+                for (int c = 0; c < NP; ++c) Bs[(c * 4 + (tid >> 7) + 2 * i) * PLANE + (tid & 127)] = pc[c];
             }
         }
     };
@@ -456,24 +526,29 @@ void gemm_bf16x3_kernel(GemmArgs p)
 #pragma unroll
         for (int st = 0; st < TK / 16; ++st) {
             // piece of B outermost, small products first: lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi
-            uint4 af[3][2];
+            uint4 af[NP][2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < NP; ++c)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) af[c][a] = As[(c * 4 + 2 * st + kh) * PLANE + wm * 64 + a * 32 + l31];
 #pragma unroll
-            for (int cb = 2; cb >= 0; --cb) {
+            for (int cb = NP - 1; cb >= 0; --cb) {
                 uint4 bf[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) bf[b] = Bs[(cb * 4 + 2 * st + kh) * PLANE + wn * 64 + b * 32 + l31];
 #pragma unroll
-                for (int ca = 2 - cb; ca >= 0; --ca)
+                for (int ca = NP - 1 - cb; ca >= 0; --ca)
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8g, af[ca][a]), __builtin_bit_cast(bf16x8g, bf[b]), acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < 2; ++b) {
+                            if (F16)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    __builtin_bit_cast(f16x8g, af[ca][a]), __builtin_bit_cast(f16x8g, bf[b]), acc[a][b], 0, 0, 0);
+                            else
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8g, af[ca][a]), __builtin_bit_cast(bf16x8g, bf[b]), acc[a][b], 0, 0, 0);
+                        }
             }
         }
     }
@@ -486,7 +561,7 @@ void gemm_bf16x3_kernel(GemmArgs p)
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
                 if (m < M && n < N) {
-                    C[(size_t)m * p.ldc + n] = acc[a][b][reg];
+                    C[(size_t)m * p.ldc + n] = F16 ? acc[a][b][reg] * unscale : acc[a][b][reg];
                 }
             }
         }
@@ -542,8 +617,14 @@ static int run_gemm(GemmArgs a, int batch, float* partial, const char* what, hip
 #if defined(RC_LAB)                    // tools/ only: force the fp32-MFMA kernel
     if (getenv("RC_BWD_FP32")) split16 = false;
 #endif
-    if (split16)
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
+    bool f16 = a.maxA && a.maxB;
+#if defined(RC_LAB)                    // tools/ only: the three-piece bf16 kernel
+    if (getenv("RC_BWD_BF16X3")) f16 = false;
+#endif
+    if (split16 && f16)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<B_K_CONTIG, true>), grid, dim3(256), 0, s, a);
+    else if (split16)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<B_K_CONTIG, false>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<B_K_CONTIG>, grid, dim3(256), 0, s, a);
     int rc = check_launch(what);
@@ -560,7 +641,8 @@ size_t build_bwd_workspace_bytes(int B, int D, int H, int W)
     // F2 in column order + dF2 in column order + the split-K planes of the larger of the two GEMMs
     const size_t p1 = gemm_ksplit(D, (int)N, (int)S0, B) > 1 ? gemm_ksplit(D, (int)N, (int)S0, B) * (size_t)B * D * N : 0;
     const size_t p2 = gemm_ksplit(D, (int)S0, (int)N, B) > 1 ? gemm_ksplit(D, (int)S0, (int)N, B) * (size_t)B * D * S0 : 0;
-    return (2 * (size_t)B * D * S0 + std::max(p1, p2)) * sizeof(float);
+    // + 3 x 128 partial maxima (|F1|, |F2|, |folded gradient|) and the fold's per-workgroup maxima behind the planes
+    return (2 * (size_t)B * D * S0 + std::max(p1, p2) + 512 + FOLD_MAX_GRID) * sizeof(float);
 }
 
 static unsigned grid_for(size_t total, unsigned cap)
@@ -588,7 +670,13 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
         rc = check_launch("corr_unpool_add_kernel");
         if (rc) return rc;
     }
+    // range pass for the fp16x2 contractions: |F1|, |F2| here, |folded gradient| by the fold kernel itself
+    float* maxima = (float*)((char*)workspace + build_bwd_workspace_bytes(B, D, H, W)) - (512 + FOLD_MAX_GRID);   // [3][128]
+    float* wgmax = maxima + 512;                             // [FOLD_MAX_GRID]
+    rc = launch_maxabs(f1, f2, (size_t)B * D * N, maxima, s);
+    if (rc) return rc;
     FoldArgs f;
+    f.wgmax = wgmax;
     const int Lf = L < 4 ? L : 4;
     f.d0 = dlv.ptr[0]; f.d1 = dlv.ptr[1]; f.d2 = dlv.ptr[2]; f.d3 = dlv.ptr[3];
     f.s0 = dlv.g[0].slab; f.s1 = dlv.g[1].slab; f.s2 = dlv.g[2].slab; f.s3 = dlv.g[3].slab;
@@ -598,11 +686,13 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     f.exact = (mant == 0.5f) && (sq * sq == (float)D);
     f.scale = 1.0f / sq; f.sqrt_d = sq;
     const size_t S0 = (size_t)dlv.g[0].slab;
-    if ((uintptr_t)dlv.ptr[0] % 16 == 0)      // slabs are multiples of 128 floats
-        hipLaunchKernelGGL(corr_fold_levels_kernel, dim3(grid_for(BN * S0 / 4, 32768)), dim3(256), 0, s, f);
-    else
-        hipLaunchKernelGGL(corr_fold_levels_scalar_kernel, dim3(grid_for(BN * S0, 16384)), dim3(256), 0, s, f);
+    const bool vec = (uintptr_t)dlv.ptr[0] % 16 == 0;        // slabs are multiples of 128 floats
+    const unsigned fold_grid = vec ? grid_for(BN * S0 / 4, FOLD_MAX_GRID) : grid_for(BN * S0, 16384);
+    if (vec) hipLaunchKernelGGL(corr_fold_levels_kernel, dim3(fold_grid), dim3(256), 0, s, f);
+    else     hipLaunchKernelGGL(corr_fold_levels_scalar_kernel, dim3(fold_grid), dim3(256), 0, s, f);
     rc = check_launch("corr_fold_levels_kernel");
+    if (rc) return rc;
+    rc = launch_maxabs1(wgmax, fold_grid, maxima + 256, s);
     if (rc) return rc;
 
     float* f2v = (float*)workspace;                 // [B][D][S0]
@@ -618,12 +708,14 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     a.A = f2v; a.B = dlv.ptr[0]; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
     a.lda = (int)S0; a.ldb = (int)S0; a.ldc = N;
     a.sA = (size_t)D * S0; a.sB = (size_t)N * S0; a.sC = (size_t)D * N;
+    a.maxA = maxima + 128; a.maxB = maxima + 256;
     rc = run_gemm<true>(a, B, planes, "gemm_f32_kernel<dF1>", s);
     if (rc) return rc;
     // dF2v[d][p] = sum_q F1[d][q] * dC0[q][p]      (B operand: n = p contiguous)
     a.A = f1; a.B = dlv.ptr[0]; a.C = df2v; a.M = D; a.N = (int)S0; a.K = N;
     a.lda = N; a.ldb = (int)S0; a.ldc = (int)S0;
     a.sA = (size_t)D * N; a.sB = (size_t)N * S0; a.sC = (size_t)D * S0;
+    a.maxA = maxima;
     rc = run_gemm<false>(a, B, planes, "gemm_f32_kernel<dF2>", s);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_cols_scatter_back_kernel, dim3(grid_for((size_t)B * D * N, 16384)), dim3(256), 0, s,
