@@ -183,7 +183,7 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldb, ldc;
     size_t sA, sB, sC;   // batch strides (elements)
-    int ksplit, kper;    // gridDim.z = batch * ksplit; kper = K range per split (multiple of 32)
+    int ksplit, kper;    // gridDim.z = batch * ksplit; kper = K range per split (multiple of 64)
     float* P;            // ksplit > 1: partial products [ksplit][batch][M][ldc]
     int batch;
     int vecA, vecB;      // 16-byte loads legal (alignment + extents)
@@ -408,10 +408,15 @@ template <bool B_K_CONTIG, bool F16>
 __global__ __launch_bounds__(256, 2)
 void gemm_bf16x3_kernel(GemmArgs p)
 {
-    constexpr int TM = 128, TN = 128, TK = 32;
+    // K tile: the loop keeps ONE tile of global loads in flight per workgroup, and an iteration is about as long as a
+    // memory round trip under load, so the bytes per tile set the pace: 64 deep for the two-piece kernel with two
+    // K-contiguous operands (365 -> 328 us at Things B=6; the n-contiguous B operand is fetched with dword loads,
+    // twice as many of them did not pay: 296 -> 301 us, and 16-byte loads + a register transpose 326 us)
+    constexpr int TM = 128, TN = 128, TK = (F16 && B_K_CONTIG) ? 64 : 32;
+    constexpr int KG = TK / 8, SL = TK / 16;          // k groups of 8 per tile; 8-k slots per thread and operand
     constexpr int NP = F16 ? 2 : 3;                   // pieces per operand
     constexpr int PLANE = 128 + 2;                    // uint4 slots per k-group plane (2 slots = 32 B of padding)
-    constexpr int OPU = NP * 4 * PLANE;               // uint4 slots per operand image
+    constexpr int OPU = NP * KG * PLANE;              // uint4 slots per operand image
     __shared__ uint4 As[OPU];
     __shared__ uint4 Bs[OPU];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -435,16 +440,16 @@ void gemm_bf16x3_kernel(GemmArgs p)
         else     split3(x, out);
     };
 
-    // staging registers: K-contiguous operand: 2 slots x 8 k (two 16-byte loads each);
-    // n-contiguous B: 2 slots (column tid & 127, k groups (tid >> 7) and + 2) x 8 dword loads
-    float xa[2][8], xb[2][8];
+    // staging registers: K-contiguous operand: SL slots x 8 k (two 16-byte loads each);
+    // n-contiguous B: SL slots (column tid & 127, k groups (tid >> 7) + 2 i) x 8 dword loads
+    float xa[SL][8], xb[SL][8];
     auto gload = [&](int k0) {
         {
             const __amdgpu_buffer_rsrc_t rs = desc(Ab + (size_t)m0 * p.lda + k0);
-            const int kg = tid & 3;
+            const int kg = tid & (KG - 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = (tid >> 2) + 64 * i;
+            for (int i = 0; i < SL; ++i) {
+                const int r = tid / KG + (256 / KG) * i;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float4 v = gemm_quad(rs, m0 + r < M, (size_t)r * p.lda, 8 * kg + 4 * h, kend - k0, 1);
@@ -454,10 +459,10 @@ void gemm_bf16x3_kernel(GemmArgs p)
         }
         if (B_K_CONTIG) {
             const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)n0 * p.ldb + k0);
-            const int kg = tid & 3;
+            const int kg = tid & (KG - 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = (tid >> 2) + 64 * i;
+            for (int i = 0; i < SL; ++i) {
+                const int r = tid / KG + (256 / KG) * i;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float4 v = gemm_quad(rs, n0 + r < N, (size_t)r * p.ldb, 8 * kg + 4 * h, kend - k0, 1);
@@ -468,7 +473,7 @@ void gemm_bf16x3_kernel(GemmArgs p)
             const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)k0 * p.ldb + n0);
             const int col = tid & 127;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SL; ++i) {
                 const int kg = (tid >> 7) + 2 * i;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -483,28 +488,28 @@ void gemm_bf16x3_kernel(GemmArgs p)
     auto lstore = [&]() {
         uint4 pc[3];
         {
-            const int kg = tid & 3;
+            const int kg = tid & (KG - 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SL; ++i) {
                 split(xa[i], scA, pc);
 #pragma unroll
-                for (int c = 0; c < NP; ++c) As[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+                for (int c = 0; c < NP; ++c) As[(c * KG + kg) * PLANE + tid / KG + (256 / KG) * i] = pc[c];
             }
         }
         if (B_K_CONTIG) {
-            const int kg = tid & 3;
+            const int kg = tid & (KG - 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SL; ++i) {
                 split(xb[i], scB, pc);
 #pragma unroll
-                for (int c = 0; c < NP; ++c) Bs[(c * 4 + kg) * PLANE + (tid >> 2) + 64 * i] = pc[c];
+                for (int c = 0; c < NP; ++c) Bs[(c * KG + kg) * PLANE + tid / KG + (256 / KG) * i] = pc[c];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SL; ++i) {
                 split(xb[i], scB, pc);
 #pragma unroll
-                for (int c = 0; c < NP; ++c) Bs[(c * 4 + (tid >> 7) + 2 * i) * PLANE + (tid & 127)] = pc[c];
+                for (int c = 0; c < NP; ++c) Bs[(c * KG + (tid >> 7) + 2 * i) * PLANE + (tid & 127)] = pc[c];
             }
         }
     };
@@ -530,12 +535,12 @@ void gemm_bf16x3_kernel(GemmArgs p)
 #pragma unroll
             for (int c = 0; c < NP; ++c)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) af[c][a] = As[(c * 4 + 2 * st + kh) * PLANE + wm * 64 + a * 32 + l31];
+                for (int a = 0; a < 2; ++a) af[c][a] = As[(c * KG + 2 * st + kh) * PLANE + wm * 64 + a * 32 + l31];
 #pragma unroll
             for (int cb = NP - 1; cb >= 0; --cb) {
                 uint4 bf[2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bf[b] = Bs[(cb * 4 + 2 * st + kh) * PLANE + wn * 64 + b * 32 + l31];
+                for (int b = 0; b < 2; ++b) bf[b] = Bs[(cb * KG + 2 * st + kh) * PLANE + wn * 64 + b * 32 + l31];
 #pragma unroll
                 for (int ca = NP - 1 - cb; ca >= 0; --ca)
 #pragma unroll
@@ -607,7 +612,7 @@ static int run_gemm(GemmArgs a, int batch, float* partial, const char* what, hip
         return fail(RAFTCORR_EUNSUPPORTED, "%s: leading dimension too large", what);
     const int ksplit = gemm_ksplit(a.M, a.N, a.K, batch);
     a.ksplit = ksplit;
-    a.kper = (((a.K + ksplit - 1) / ksplit) + 31) / 32 * 32;
+    a.kper = (((a.K + ksplit - 1) / ksplit) + 63) / 64 * 64;         // a multiple of every kernel's K tile
     a.P = partial; a.batch = batch;
     a.vecA = (a.lda % 4 == 0) && (a.K % 4 == 0) && (((uintptr_t)a.A | (a.sA * 4)) % 16 == 0);
     a.vecB = (a.ldb % 4 == 0) && ((B_K_CONTIG ? a.K : a.N) % 4 == 0) && (((uintptr_t)a.B | (a.sB * 4)) % 16 == 0);
