@@ -230,7 +230,9 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
                             const float* coords, float* out, void* stream);
 
 /* raftcorr_alt_lookup_fwd with the query tiles formed by WINDOW position instead of pixel position: same arguments,
- * same results bit for bit (a query's outputs do not depend on which queries share its tile), one more small launch.
+ * same results up to the last bit of a sum, also from run to run (a query's taps do not depend on which queries share
+ * its tile, but the tile's box does, and a window split over two passes of a box adds its halves in another order;
+ * tile membership follows the order of the bucket kernel's atomics), one more small launch.
  * A pixel tile's cost grows with the disagreement of its 64 flow vectors (the product covers the bounding box of their
  * windows); tiles of queries whose window centres share an 8x8 target cell cost the same for any flow field.
  * workspace: raftcorr_alt_lookup_fwd_sorted_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care. */

@@ -624,7 +624,8 @@ class AlternateCorrBlock:
     right choice for flow fields (neighbours look at neighbouring windows).  "window": queries are dealt into tiles by
     the position of their windows in a small extra launch per call (raftcorr_alt_lookup_fwd_sorted) -- the cost no
     longer depends on how coherent the flow is (per-pixel random offsets of a few pixels cost pixel tiles 2-4x);
-    about 10 us per call more when the flow is smooth.  Same results (last-bit differences)."""
+    about 10 us per call more when the flow is smooth.  Same results up to the last bit of a sum -- also from run to
+    run: tile membership follows the order of the bucket kernel's atomics (pixel tiles are bit-reproducible)."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, tiles="pixel"):
         self.num_levels = num_levels

@@ -268,7 +268,8 @@ def test_step_is_hip_graph_capturable(dev):
     def step():
         cb = CorrBlock(f1, f2, num_levels=L, radius=r)
         alt = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)
-        return [cb(c) for c in cos] + [alt(cos[-1])]
+        win = AlternateCorrBlock(f1, f2, num_levels=L, radius=r, tiles="window")
+        return [cb(c) for c in cos] + [alt(cos[-1]), win(cos[-1])]
 
     with torch.no_grad():
         side = torch.cuda.Stream()
@@ -284,8 +285,11 @@ def test_step_is_hip_graph_capturable(dev):
             graph.replay()
             torch.cuda.synchronize()
             eager = step()
-            for a, b in zip(outs, eager):
+            for a, b in zip(outs[:-1], eager[:-1]):
                 assert torch.equal(a, b), trial
+            # window tiles: which queries share a tile depends on the order of the bucket kernel's atomics, and with it
+            # the split of a window over the passes of a box: equal up to the last bit of a sum, not bit for bit
+            assert rel_err(outs[-1].cpu().numpy(), eager[-1].cpu().numpy()) <= 1e-6, trial
 
 
 def test_lookup_backward_accumulates_across_iterations(dev):
