@@ -25,7 +25,7 @@
 //    (target tile, channel group, split s of the list of overlapping query tiles); level 0 stores directly, the
 //    coarser levels (few target tiles, each touched by hundreds of query tiles) write per-split partial tiles that a
 //    small second kernel adds in a fixed order.  The list comes from a table of per-(level, query tile) window
-//    bounding boxes (alt_windows_kernel) and is walked in increasing tile order: the summation order never changes.
+//    bounding boxes (alt_bwd_pre_kernel) and is walked in increasing tile order: the summation order never changes.
 #include "common.h"
 #include "alt_common.h"
 #include <algorithm>
@@ -41,6 +41,7 @@ constexpr int GW = NH * CG;                       // channels per workgroup
 constexpr int IMG_A = TQ * 16;                    // uint4 slots of the G image  [64 rows][16 slots]
 constexpr int IMG_B = CG * 16;                    // uint4 slots of the partner image [CG channel rows][16 slots]
 constexpr int MAXSPLIT = 32;
+constexpr int DMAXP = 512;                        // partial maxima of |d(out)| (alt_bwd_pre_kernel)
 
 struct AltBwdArgs {
     const uint4* f1t;                             // tile-major fmap1: [B][qtiles][Cp][16 slots]
@@ -49,7 +50,7 @@ struct AltBwdArgs {
     const float* coords;                          // (B, 2, H, W)
     const float* dout;                            // (B, L*rd*rd, H, W)
     const float* maxpart;                         // [2][128] partial maxima of |fmap1|, |fmap2| (pack scales)
-    const float* dmax;                            // [128] partial maxima of |dout|
+    const float* dmax;                            // [DMAXP] partial maxima of |dout|
     float* df1;                                   // (B, H, W, C)
     float* df2[RAFTCORR_MAX_LEVELS];              // (B, H_l, W_l, C)
     int4* boxes;                                  // [B][L][qtiles]: (xmin, xmax, ymin, ymax) of the tile's windows at level l
@@ -72,6 +73,15 @@ struct BwdSh {
     int list[256];
     int wc[4];
 };
+
+// exponent that maps max|d(out)| into [2^14, 2^15): every wave reduces the DMAXP partial maxima itself
+__device__ __forceinline__ int dout_exp(const AltBwdArgs& p, int lane)
+{
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < DMAXP / 64; ++i) m = fmaxf(m, p.dmax[lane + 64 * i]);
+    return range_exp16(wave_max128(m));
+}
 
 __device__ __forceinline__ int ttx_of(const AltBwdArgs& p, int l) { return (p.wl[l] + 7) >> 3; }
 __device__ __forceinline__ int ttiles_of(const AltBwdArgs& p, int l) { return ttx_of(p, l) * ((p.hl[l] + 7) >> 3); }
@@ -117,11 +127,39 @@ void alt_pack_tiles_kernel(PackSet ps)
 }
 
 // ---------------------------------------------------------------------------------------------
-// per (batch, level, query tile): the 64 windows (origin + fractions) and their bounding box.  grid B * L * qtiles, block 64
+// The two small passes in front of the main kernel, in one launch (they do not depend on each other):
+//   workgroups [0, B * L * qtiles): per (batch, level, query tile) the 64 windows (origin + fractions) and their bounding box;
+//   the DMAXP workgroups after them: partial maxima of |d(out)| (n floats), the range of the G images.
+// block 64
 __global__ __launch_bounds__(64)
-void alt_windows_kernel(AltBwdArgs p)
+void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)
 {
     __shared__ TileQ sh;
+    if ((int)blockIdx.x >= nwin) {
+        const int j = blockIdx.x - nwin, lane = threadIdx.x;
+        const float* __restrict__ x = p.dout;
+        float m = 0.f;
+        const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;       // 16-byte loads when aligned
+        constexpr size_t STRIDE = (size_t)DMAXP * 64;
+        size_t i = (size_t)j * 64 + lane;
+        for (; i + 3 * STRIDE < n4; i += 4 * STRIDE) {                   // four loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ((const float4*)x)[i + u * STRIDE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+        }
+        for (; i < n4; i += STRIDE) {
+            const float4 v = ((const float4*)x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (size_t t = n4 * 4 + (size_t)j * 64 + lane; t < n; t += STRIDE) m = fmaxf(m, fabsf(x[t]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) const_cast<float*>(p.dmax)[j] = m;
+        return;
+    }
     const int tile = blockIdx.x % p.qtiles, bl = blockIdx.x / p.qtiles;
     Tile16 t;
     t.l = bl % p.L; t.b = bl / p.L;
@@ -358,7 +396,7 @@ void alt_bwd_kernel(AltBwdArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mb = wave & 1, nb0 = wave >> 1;
     const int rd = 2 * p.r + 1, rd2 = rd * rd;
-    const int eg = range_exp16(wave_max128(fmaxf(p.dmax[lane], p.dmax[lane + 64])));
+    const int eg = dout_exp(p, lane);
     const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
     const int e2 = range_exp16(wave_max128(fmaxf(p.maxpart[MAXPARTS16 + lane], p.maxpart[MAXPARTS16 + lane + 64])));
     const float sg = ldexpf(1.0f, eg);
@@ -525,7 +563,7 @@ __global__ __launch_bounds__(256)
 void alt_bwd_reduce_kernel(AltBwdArgs p)
 {
     const int lane = threadIdx.x & 63, l = blockIdx.y;
-    const int eg = range_exp16(wave_max128(fmaxf(p.dmax[lane], p.dmax[lane + 64])));
+    const int eg = dout_exp(p, lane);
     const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
     const int nsplit = p.nsplit[l];
     if (nsplit <= 1) return;
@@ -587,7 +625,7 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
         pl.poff[l] = pf;
         if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
     }
-    pl.off_boxes = 512;                                      // [0, 512): partial maxima of |dout|
+    pl.off_boxes = DMAXP * sizeof(float);                    // in front: partial maxima of |dout|
     pl.off_wins = (pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles + 255) / 256 * 256;
     pl.off_partial = (pl.off_wins + sizeof(int4) * (size_t)B * L * pl.qtiles * TQ + 255) / 256 * 256;
     pl.bytes = pl.off_partial + pf * sizeof(float);
@@ -653,10 +691,9 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     a.sqrt_c = sqrtf((float)C);
     a.accumulate = accumulate;
     const int rd2 = (2 * r + 1) * (2 * r + 1);
-    int rc = launch_maxabs1(dout, (size_t)B * L * rd2 * H * W, (float*)workspace, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(alt_windows_kernel, dim3(B * L * pl.qtiles), dim3(64), 0, s, a);
-    rc = check_launch("alt_windows_kernel");
+    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3(B * L * pl.qtiles + DMAXP), dim3(64), 0, s, a, B * L * pl.qtiles,
+                       (size_t)B * L * rd2 * H * W);
+    int rc = check_launch("alt_bwd_pre_kernel");
     if (rc) return rc;
     const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * std::max(rd2, 96) * sizeof(float);
     static thread_local bool allowed[64] = {};               // > 64 KiB of dynamic LDS: opt in once per device

@@ -113,6 +113,16 @@ def test_training_step_gradients_match_reference_corr(dev):
                              if p.grad is not None}
 
     l_ref, g_ref = grads(lambda a, b: O.CorrBlockOracle(a, b, 4, 4))
+    # The model around the correlation block is stock PyTorch, and its convolution kernels are not reproducible from
+    # run to run on this stack: the REFERENCE against itself (tools/train_grad_diag.py ref, 4 runs x 3 processes)
+    # differs by 1e-6 .. 9e-4 of a parameter's scale (update_block.flow_head.conv1.bias, encoder.convf1.bias,
+    # encoder.convc1.weight), in a few discrete steps -- kernel selection, not rounding.  The bar is therefore the
+    # noise floor measured here (two more reference runs) plus a margin of 2e-3 of the parameter's scale; a wrong
+    # correlation gradient shows up at 1e-1 and more.
+    noise = {k: 0.0 for k in g_ref}
+    for _ in range(2):
+        _, g_again = grads(lambda a, b: O.CorrBlockOracle(a, b, 4, 4))
+        noise = {k: max(noise[k], float(np.abs(g_ref[k] - g_again[k]).max())) for k in g_ref}
     l_our, g_our = grads(lambda a, b: CorrBlock(a, b, num_levels=4, radius=4))
     assert abs(l_ref - l_our) <= 1e-5 * abs(l_ref)
     assert g_ref.keys() == g_our.keys() and any(k.startswith("fnet.") for k in g_ref)
@@ -121,5 +131,6 @@ def test_training_step_gradients_match_reference_corr(dev):
     for k in g_ref:       # parameters in front of a norm layer have a zero gradient (1e-8 noise): atol
         scale = np.abs(g_ref[k]).max()
         worst = max(worst, float(np.abs(g_ref[k] - g_our[k]).max() / (scale + 1e-2 * gmax)))
-        assert np.abs(g_ref[k] - g_our[k]).max() <= 1e-4 * scale + 1e-5 * gmax, k
-    print(f"train-step gradients: worst per-parameter difference {worst:.1e} of its scale")
+        assert np.abs(g_ref[k] - g_our[k]).max() <= 2e-3 * scale + 1e-5 * gmax + 4.0 * noise[k], (k, noise[k])
+    print(f"train-step gradients: worst per-parameter difference {worst:.1e} of its scale; "
+          f"reference against itself: {max(noise.values()) / gmax:.1e} of the largest gradient")
