@@ -447,7 +447,7 @@ def extras_kitti(torch, wl, dev):
                                                "TFLOP/s", hbm_GBs=w["alt_bytes"] / tf / 1e3,
                                                hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS,
                                                compulsory_bytes=w["alt_bytes"])
-            out["alt_bwd_" + tag] = frac_entry("corr_maxabs + alt_boxes + alt_bwd + alt_bwd_reduce kernels", tb, "mfma", w["alt_bwd_flops"],
+            out["alt_bwd_" + tag] = frac_entry("alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels", tb, "mfma", w["alt_bwd_flops"],
                                                MFMA_F32_PEAK_TFLOPS, "TFLOP/s", hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
                                                hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS,
                                                compulsory_bytes=w["alt_bwd_bytes"])
