@@ -284,9 +284,9 @@ class ThingsTrain(Workload):
         super().__init__(*a)
         self.f1.requires_grad_(True)
         self.f2.requires_grad_(True)
-        self.bucket = None
-        if self.world > 1:          # the DDP gradient bucket of the model around the path (config 3)
-            self.bucket = self.torch.zeros(GRAD_BUCKET, dtype=self.torch.float32, device=self.dev)
+        from raft_amd.sharding import GradBucket
+        # the DDP gradient bucket of the model around the path (config 3): a dummy of RAFT-basic's size, no-op at N = 1
+        self.bucket = GradBucket(GRAD_BUCKET, self.dev)
 
     def step(self, ev):
         from raft_amd import CorrBlock
@@ -298,9 +298,9 @@ class ThingsTrain(Workload):
         outs = [cb(c) for c in self.coords]
         if ev:
             ev[1].record()
+        self.bucket.start()                     # async: overlaps the backward kernels, as DDP's buckets do
         self.torch.autograd.backward(outs, self.gouts)
-        if self.bucket is not None:
-            self.dist.all_reduce(self.bucket)
+        self.bucket.finish()
         if ev:
             ev[2].record()
         return self.f1.grad
@@ -687,11 +687,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        if dry:
-            dist.init_process_group(backend)
-        else:
-            dist.init_process_group(backend, device_id=dev)
+        from raft_amd.sharding import init_ranks
+        dist = init_ranks(backend, dev)
     ranks_seen = dist.get_world_size() if dist is not None else 1
 
     def sync():
@@ -711,8 +708,18 @@ def main():
         class Dry:
             n_events = 3
 
+            def __init__(self):
+                from raft_amd.sharding import GradBucket
+                # config 3's collective runs in the dry mode too (gloo, CPU tensors): the same GradBucket calls as
+                # ThingsTrain.step, so the N > 1 plumbing is executable without a GPU
+                self.bucket = GradBucket(GRAD_BUCKET, dev) if args.config == "things_train" else None
+
             def step(self, ev):
+                if self.bucket is not None:
+                    self.bucket.start()
                 time.sleep(0.001)
+                if self.bucket is not None:
+                    self.bucket.finish()
         wl = Dry()
     else:
         wl = WORKLOADS[args.config](torch, args.config, dev, rank, world, dist)
@@ -753,7 +760,8 @@ def main():
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
     if dry:
-        line.update({"dry_run": True, "config": {"workload": "DRY RUN: launcher and rank plumbing only, no kernels"}})
+        line.update({"dry_run": True, "config": {"workload": "DRY RUN: launcher and rank plumbing only, no kernels"},
+                     "allreduces_launched": getattr(getattr(wl, "bucket", None), "launched", 0)})
         print(json.dumps(line), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -770,8 +778,10 @@ def main():
     line["config"] = {"workload": f"{args.config}: {img_h}x{img_w} -> {H}x{W} (N={H * W}), batch {B}/GPU, D={D}, {what} "
                                   f"[BASELINE.json configs[{bidx}]]",
                       "parallelism": f"{ranks_seen} independent replica(s) (batch-sharded pairs"
-                                     + (", DDP-sized gradient all-reduce per step)" if args.config == "things_train" and world > 1
-                                        else ", no collective)")}
+                                     + (f", one async all-reduce per step of a DUMMY bucket of {GRAD_BUCKET} fp32 = "
+                                        f"{GRAD_BUCKET * 4 / 1e6:.0f} MB (zeros, not gradients: DDP-sized traffic), issued before "
+                                        "the backward kernels and waited for after them)"
+                                        if args.config == "things_train" and world > 1 else ", no collective)")}
     if args.config == "1080p":
         line["dtype"] = "bf16"
     d = kernels[dom]

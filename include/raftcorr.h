@@ -149,8 +149,12 @@ int raftcorr_lookup_fwd(const float* const* levels, int B, int H, int W, int num
  * `convc1` + bias + ReLU (core/update.py:83,90: cor = F.relu(self.convc1(corr))):
  *   out[b, c, q] = act( sum_k weight[c, k] * lookup(coords)[b, k, q] + bias[c] ),  k = l*rd*rd + a*rd + b
  * canonical coordinates (RAFTCORR_MODE_CANONICAL), num_levels <= 4, radius 3 or 4.  The
- * (B, L*rd*rd, H, W) lookup result is never written to memory; the product runs on the fp32
- * matrix cores (exact fp32 FMA chain).  Forward only (inference).
+ * (B, L*rd*rd, H, W) lookup result is never written to memory; the product runs on the 16-bit
+ * matrix cores in the bf16x3 scheme of raftcorr_build_pyramid_prec (lookup tile and weight split into
+ * three bfloat16 pieces, six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation, partial sums added
+ * in a fixed order): fp32-grade, bit-reproducible.  This entry point is the forward pass; the Python
+ * host differentiates it (raft_amd/corr.py:_LookupConv: the lookup is re-created with
+ * raftcorr_lookup_fwd, W^T d(pre) goes through raftcorr_lookup_bwd / the deferred backward below).
  * The weight is packed once per model with raftcorr_conv1x1_pack_weight (weight: (Cout, Cin) row-major
  * = the conv's (Cout, Cin, 1, 1) tensor; packed: raftcorr_conv1x1_packed_bytes(Cout, Cin) bytes of
  * device memory).  bias: (Cout) or NULL.  relu: 0/1.  out: (B, Cout, H, W), overwritten. */

@@ -51,6 +51,54 @@ def test_two_rank_gloo_timing_and_sharding():
     assert d0 == d1 == 13.0           # whole-job units = sum over ranks
 
 
+def _bucket_worker(rank, world, port, q):
+    """What bench.py's main() and ThingsTrain.step do for N > 1: init_ranks + GradBucket.start / finish."""
+    from raft_amd.sharding import GradBucket, init_ranks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    d = init_ranks("gloo", torch.device("cpu"))
+    b = GradBucket(5_257_536, torch.device("cpu"))          # bench.py's GRAD_BUCKET
+    b.buf.fill_(float(rank + 1))
+    b.start()
+    x = torch.ones(4).sum().item()                          # "backward" work between issue and wait
+    b.finish()
+    first = (float(b.buf[0]), float(b.buf[-1]))
+    b.start(); b.finish()                                   # a second step reuses the bucket
+    q.put((rank, first, float(b.buf[7]), b.launched, x))
+    d.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_two_ranks_gloo():
+    """The bench's only collective (config 3) through the same function bench.py calls, 2 CPU ranks over gloo,
+    async issue + wait: SUM over ranks, bucket reusable from step to step; no-op without a process group."""
+    from raft_amd.sharding import GradBucket
+    solo = GradBucket(16, torch.device("cpu"))
+    solo.start(); solo.finish()
+    assert solo.buf is None and solo.launched == 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, first, second, launched, _ in res:
+        assert first == (3.0, 3.0) and second == 6.0 and launched == 2
+
+
+def test_bench_things_train_dry_two_ranks_runs_the_allreduce():
+    """`bench.py --config things_train --gpus 2 --device cpu`: the dry mode makes the same GradBucket calls per step
+    as ThingsTrain.step, over gloo: one all-reduce per warm-up and timed step."""
+    out, line = _run_bench(["--gpus", "2", "--config", "things_train"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["ranks_seen"] == 2 and line["dry_run"] is True
+    assert line["allreduces_launched"] == line["steps"] + line["warmup_steps_run"] == 4
+
+
 def test_train_step_harness_two_ranks_gloo():
     """tools/train_step.py (DDP train-step harness) wired correctly for N > 1: two
     CPU ranks over gloo with the stock-operator correlation block (the product kernels need a

@@ -93,9 +93,79 @@ def test_flow_with_bf16_build_stays_close(dev, reference_flows):
     assert _epe(ours[11], reference_flows[11]) <= 0.05
 
 
+class _Recording:
+    """Correlation factory that keeps what crosses the block's boundary in a training step: the two feature maps,
+    every lookup's coordinates and -- through hooks -- the gradient that arrives at every lookup's output and the
+    gradients the block hands back to the feature maps."""
+
+    def __init__(self, make):
+        self.make, self.f, self.df, self.coords, self.douts = make, [], [None, None], [], {}
+
+    def __call__(self, fmap1, fmap2):
+        self.f = [fmap1, fmap2]
+        for i, t in enumerate(self.f):
+            t.register_hook(lambda g, i=i: self.df.__setitem__(i, g.detach().clone()))
+        blk = self.make(fmap1, fmap2)
+
+        def lookup(coords):
+            k = len(self.coords)
+            self.coords.append(coords.detach().clone())
+            out = blk(coords)
+            out.register_hook(lambda g, k=k: self.douts.__setitem__(k, g.detach().clone()))
+            return out
+        return lookup
+
+
 def test_training_step_gradients_match_reference_corr(dev):
-    """One training step's gradients (sequence loss over 4 iterations, core/train_origin.py:49-79)
-    w.r.t. every encoder / update-block parameter: ours vs the oracle's CorrBlock under autograd."""
+    """One training step (sequence loss over 4 iterations, core/train_origin.py:49-79; freeze_bn as core/raft.py:60-63).
+    The quantity under test is what the correlation block hands back: d(loss)/d(fmap1), d(loss)/d(fmap2).  The model
+    around the block is stock PyTorch and its MIOpen convolutions are not reproducible from run to run (the reference
+    against itself moves parameters by up to 9e-4 of their scale, tools/train_grad_diag.py), so the block is
+    ISOLATED: the step runs once with this library's block, the tensors at the block's boundary are recorded (feature
+    maps, the 4 lookups' coordinates, the 4 upstream gradients), and the reference's CorrBlock (oracle restatement,
+    autograd through matmul / avg_pool2d / grid_sample) is replayed on exactly those tensors.  Bar: 1e-5 of each batch
+    item's gradient scale, both maps, both blocks -- no noise margin."""
+    from conftest import rel_err_by_item
+    from oracle import corr_oracle as O
+    from raft_amd import AlternateCorrBlock, CorrBlock
+
+    def step(make):
+        torch.manual_seed(0)
+        rec = _Recording(make)
+        model = RAFT(rec).to(dev).train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
+        i1, i2, gt = synthetic_pair(2, 136, 176, seed=3, device=dev)
+        preds = model(i1, i2, iters=4)
+        loss, _ = sequence_loss(preds, gt, torch.ones_like(gt[:, 0]))
+        loss.backward()
+        grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+        return rec, float(loss.detach()), grads
+
+    for name, make in (("all_pairs", lambda a, b: CorrBlock(a, b, num_levels=4, radius=4)),
+                       ("on_the_fly", lambda a, b: AlternateCorrBlock(a, b, num_levels=4, radius=4))):
+        rec, loss, grads = step(make)
+        assert len(rec.coords) == 4 and sorted(rec.douts) == [0, 1, 2, 3] and rec.df[0] is not None and rec.df[1] is not None
+        assert any(k.startswith("fnet.") and np.abs(g).max() > 0 for k, g in grads.items())      # the gradient reached the encoder
+        f1 = rec.f[0].detach().float().cpu().requires_grad_(True)
+        f2 = rec.f[1].detach().float().cpu().requires_grad_(True)
+        ref = O.CorrBlockOracle(f1, f2, 4, 4)
+        torch.autograd.backward([ref(c.cpu()) for c in rec.coords], [rec.douts[k].cpu() for k in range(4)])
+        e1 = rel_err_by_item(rec.df[0].cpu().numpy(), f1.grad.numpy())
+        e2 = rel_err_by_item(rec.df[1].cpu().numpy(), f2.grad.numpy())
+        print(f"train step, {name}: d fmap1 {max(e1):.2e}, d fmap2 {max(e2):.2e} of the item's scale (loss {loss:.4f})")
+        # the on-the-fly block samples in pixel coordinates (its reference: the CUDA kernel), the replayed reference is the
+        # all-pairs block with its coordinate round trip: 3e-5 between the reference's own two paths (test_gpu_parity K1)
+        bar = 1e-5 if name == "all_pairs" else 3e-5
+        assert max(e1) <= bar and max(e2) <= bar, (name, e1, e2)
+
+
+def test_training_step_parameter_gradients_sanity(dev):
+    """The same step judged at the PARAMETERS (every encoder / update-block weight), ours vs the oracle's CorrBlock
+    inside the same stock model: loss equal to 1e-5, every parameter gradient within the stock model's own
+    run-to-run differences (measured here: three reference runs) plus 1e-4 of its scale.  A wiring check around the
+    isolated test above, which carries the tight bar; a wrong correlation gradient shows up at 1e-1 and more."""
     from oracle import corr_oracle as O
     from raft_amd import CorrBlock
 
@@ -113,12 +183,6 @@ def test_training_step_gradients_match_reference_corr(dev):
                              if p.grad is not None}
 
     l_ref, g_ref = grads(lambda a, b: O.CorrBlockOracle(a, b, 4, 4))
-    # The model around the correlation block is stock PyTorch, and its convolution kernels are not reproducible from
-    # run to run on this stack: the REFERENCE against itself (tools/train_grad_diag.py ref, 4 runs x 3 processes)
-    # differs by 1e-6 .. 9e-4 of a parameter's scale (update_block.flow_head.conv1.bias, encoder.convf1.bias,
-    # encoder.convc1.weight), in a few discrete steps -- kernel selection, not rounding.  The bar is therefore the
-    # noise floor measured here (two more reference runs) plus a margin of 2e-3 of the parameter's scale; a wrong
-    # correlation gradient shows up at 1e-1 and more.
     noise = {k: 0.0 for k in g_ref}
     for _ in range(2):
         _, g_again = grads(lambda a, b: O.CorrBlockOracle(a, b, 4, 4))
@@ -127,10 +191,11 @@ def test_training_step_gradients_match_reference_corr(dev):
     assert abs(l_ref - l_our) <= 1e-5 * abs(l_ref)
     assert g_ref.keys() == g_our.keys() and any(k.startswith("fnet.") for k in g_ref)
     gmax = max(np.abs(g).max() for g in g_ref.values())
+    floor = max(noise.values())                                 # the stock model against itself, worst parameter
     worst = 0.0
     for k in g_ref:       # parameters in front of a norm layer have a zero gradient (1e-8 noise): atol
         scale = np.abs(g_ref[k]).max()
         worst = max(worst, float(np.abs(g_ref[k] - g_our[k]).max() / (scale + 1e-2 * gmax)))
-        assert np.abs(g_ref[k] - g_our[k]).max() <= 2e-3 * scale + 1e-5 * gmax + 4.0 * noise[k], (k, noise[k])
-    print(f"train-step gradients: worst per-parameter difference {worst:.1e} of its scale; "
-          f"reference against itself: {max(noise.values()) / gmax:.1e} of the largest gradient")
+        assert np.abs(g_ref[k] - g_our[k]).max() <= 1e-4 * scale + 1e-5 * gmax + 4.0 * max(noise[k], floor), (k, noise[k], floor)
+    print(f"train-step parameter gradients: worst difference {worst:.1e} of a parameter's scale; "
+          f"reference against itself: {floor / gmax:.1e} of the largest gradient")
