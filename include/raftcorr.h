@@ -188,6 +188,32 @@ int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int
                        float* dfmap1, float* dfmap2, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* Deferred form of the two calls above (same reference lines: grid_sampler_2d_backward per lookup behind
+ * core/utils/utils.py:65, then avg_pool2d_backward / scale / bmm backward behind core/corr.py:26,59,61), for the
+ * training path where ONE frame pair is looked up K times (core/raft.py:123-125) before autograd reaches the build:
+ * a lookup's backward pass only records its (coords, d(out)); raftcorr_build_bwd_deferred then makes every query's
+ * folded level-0 gradient row in LDS from all K records and all levels and writes it once -- no dense gradient
+ * pyramid is zero-filled, read-modified-written per lookup or folded in a separate pass.
+ *   raftcorr_lookup_bwd_record   canonical-mode d(out) (B, channels, H, W) -> record (B, H*W, channels), the layout the
+ *                         fold reads (a query's channels contiguous); channels = L*rd*rd.  Fork-mode d(out)
+ *                         (B, N, channels) IS a record already.
+ *   raftcorr_build_bwd_deferred  coords / records: HOST arrays of n_lookups DEVICE pointers (coords as given to the
+ *                         lookup: (B,N,2) fork, (B,2,H,W) canonical; any order: the sum runs in array order, the same
+ *                         bits on every run).  dlevels: NULL, or a dense pyramid gradient as raftcorr_build_bwd takes it
+ *                         (someone differentiated the pyramid tensors directly): folded first, the records are added;
+ *                         its level 0 is clobbered.  dfmap1, dfmap2 (B,D,H,W) overwritten.  workspace:
+ *                         raftcorr_build_bwd_deferred_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care.
+ *   raftcorr_build_bwd_deferred_supported  1 when the shape fits (num_levels <= 4, radius <= 7, the query's level rows
+ *                         + staged records <= 150 KiB of LDS: up to ~190 x 190 maps at 4 levels), else 0: use
+ *                         raftcorr_lookup_bwd + raftcorr_build_bwd. */
+int64_t raftcorr_build_bwd_deferred_workspace_bytes(int B, int D, int H, int W);
+int raftcorr_build_bwd_deferred_supported(int H, int W, int num_levels, int radius);
+int raftcorr_lookup_bwd_record(const float* dout, int B, int H, int W, int channels, float* record, void* stream);
+int raftcorr_build_bwd_deferred(const float* fmap1, const float* fmap2, int B, int D, int H, int W, int num_levels,
+                                int radius, int mode, int n_lookups, const float* const* coords,
+                                const float* const* records, float* const* dlevels, float* dfmap1, float* dfmap2,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Drop-in for alt_cuda_corr.forward (alt_cuda_corr/correlation.cpp:23-33 ->
  * correlation_kernel.cu:260-286): one level of on-the-fly correlation.
  * fmap1 (B,H1,W1,C), fmap2 (B,H2,W2,C), coords (B,N,H1,W1,2) -> corr (B,N,rd*rd,H1,W1),

@@ -52,6 +52,11 @@ _SIGNATURES = {
     "raftcorr_build_bwd": ([_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                             ctypes.POINTER(ctypes.c_void_p), _c_fp, _c_fp, _c_fp, ctypes.c_int64,
                             ctypes.c_void_p], _c_int),
+    "raftcorr_build_bwd_deferred_workspace_bytes": ([_c_int] * 4, ctypes.c_int64),
+    "raftcorr_build_bwd_deferred_supported": ([_c_int] * 4, _c_int),
+    "raftcorr_lookup_bwd_record": ([_c_fp] + [_c_int] * 4 + [_c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_build_bwd_deferred": ([_c_fp, _c_fp] + [_c_int] * 8 + [ctypes.POINTER(ctypes.c_void_p)] * 3 +
+                                    [_c_fp, _c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_forward": ([_c_fp, _c_fp, _c_fp, _c_fp] + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
     "raftcorr_alt_backward": ([_c_fp] * 7 + [_c_int] * 8 + [ctypes.c_void_p], _c_int),
     "raftcorr_alt_packed_bytes": ([_c_int] * 4, ctypes.c_int64),

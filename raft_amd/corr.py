@@ -108,6 +108,12 @@ class _Pyramid:
         self.dptrs = None
         self.dtask = None         # autograd graph task that owns the accumulator's contents
         self._index = {}
+        # deferred backward (raftcorr_build_bwd_deferred): the lookups of a backward pass only record (coords, d(out)),
+        # the build node turns all of them into the folded level-0 gradient in one kernel.  Shapes it does not take
+        # (more than 4 levels, very large maps) keep the accumulate-then-fold route.
+        self.deferred = False
+        self.records = []         # [(mode, radius, coords, record (B, N, C))] of the running backward pass
+        self.rtask = None
 
     def out_shape(self, radius, mode):
         shape = self._shapes.get((radius, mode))
@@ -165,6 +171,28 @@ class _Pyramid:
         self.dflat = None
         self.dptrs = None
 
+    def set_deferred(self, radius):
+        self.deferred = bool(_lib.load().raftcorr_build_bwd_deferred_supported(self.H, self.W, self.L, radius))
+
+    def add_record(self, mode, radius, coords, rec):
+        """A lookup's (coords, d(out) as (B, N, C)) for the backward pass that is running now; what an earlier pass
+        left behind without reaching the build node is dropped (cf. grad_buffer)."""
+        task = _graph_task_id()
+        if self.rtask != task:
+            self.records = []
+        self.rtask = task
+        self.records.append((mode, radius, coords, rec))
+
+    def records_take(self, mode):
+        """One deferred launch serves one coordinate convention: a block that is looked up in both conventions inside
+        one backward pass sends the second convention's lookups through the dense accumulator."""
+        return self.rtask != _graph_task_id() or not self.records or self.records[0][0] == mode
+
+    def take_records(self):
+        recs = self.records if self.rtask == _graph_task_id() else []
+        self.records, self.rtask = [], None
+        return recs
+
 
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)
 
@@ -182,6 +210,19 @@ def _build(fmap1, fmap2, pyr, precision="fp32"):
                                                   pyr.ptrs, work.data_ptr(), wbytes,
                                                   _lib.PRECISIONS[precision], pyr.vol, _stream(fmap1)), "build_pyramid")
     return flat
+
+
+def _record(pyr, mode, radius, coords, dout):
+    """Note a lookup's gradient for the deferred backward: fork-mode d(out) (B, N, C) is the record itself, canonical
+    d(out) (B, C, H, W) is transposed to (B, N, C) by raftcorr_lookup_bwd_record."""
+    if mode == _lib.MODE_FORK:
+        rec = dout
+    else:
+        B, C = dout.shape[:2]
+        rec = torch.empty(B, pyr.N, C, dtype=torch.float32, device=dout.device)
+        _lib.check(_lib.load().raftcorr_lookup_bwd_record(dout.data_ptr(), B, pyr.H, pyr.W, C, rec.data_ptr(), _stream(dout)),
+                   "lookup_bwd_record")
+    pyr.add_record(mode, radius, coords, rec)
 
 
 class _BuildPyramid(torch.autograd.Function):
@@ -207,13 +248,31 @@ class _BuildPyramid(torch.autograd.Function):
         if dflat is not None:                       # someone differentiated corr_pyramid directly
             acc = pyr.grad_buffer()
             acc += dflat
-        if not pyr.pending_grad():
+        recs = pyr.take_records()
+        if not pyr.pending_grad() and not recs:
             pyr.release_grad()
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None, None
         lib = _lib.load()
         B, D, H, W = fmap1.shape
         d1 = torch.empty_like(fmap1)
         d2 = torch.empty_like(fmap2)
+        if recs:
+            # deferred lookups (+ the dense accumulator when something wrote into it): one kernel builds the folded
+            # level-0 gradient from all records.  Lookups of one block share mode and radius.
+            mode, radius = recs[0][0], recs[0][1]
+            dense = pyr.pending_grad()
+            wbytes = lib.raftcorr_build_bwd_workspace_bytes(B, D, H, W) if dense else \
+                lib.raftcorr_build_bwd_deferred_workspace_bytes(B, D, H, W)
+            work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
+            cptrs = _lib.ptr_array([r[2] for r in recs])
+            rptrs = _lib.ptr_array([r[3] for r in recs])
+            with _guard(fmap1):
+                _lib.check(lib.raftcorr_build_bwd_deferred(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L, radius, mode,
+                                                           len(recs), cptrs, rptrs, pyr.dptrs if dense else None,
+                                                           d1.data_ptr(), d2.data_ptr(), work.data_ptr(), wbytes,
+                                                           _stream(fmap1)), "build_bwd_deferred")
+            pyr.release_grad()
+            return d1, d2, None, None
         wbytes = lib.raftcorr_build_bwd_workspace_bytes(B, D, H, W)
         work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
         with _guard(fmap1):
@@ -271,13 +330,16 @@ class _Lookup(torch.autograd.Function):
         dcoords = torch.empty_like(coords) if need_co else None
         with _guard(coords):
             dptrs = None
-            if need_vol:
+            if need_vol and pyr.deferred and pyr.records_take(ctx.mode):
+                _record(pyr, ctx.mode, ctx.radius, coords, dout)
+            elif need_vol:
                 pyr.grad_buffer()
                 dptrs = pyr.dptrs
-            _lib.check(lib.raftcorr_lookup_bwd(pyr.ptrs, dptrs, pyr.B, pyr.H, pyr.W, pyr.L, ctx.radius,
-                                               coords.data_ptr(), ctx.mode, dout.data_ptr(),
-                                               dcoords.data_ptr() if need_co else None,
-                                               _stream(coords)), "lookup_bwd")
+            if dptrs is not None or need_co:
+                _lib.check(lib.raftcorr_lookup_bwd(pyr.ptrs, dptrs, pyr.B, pyr.H, pyr.W, pyr.L, ctx.radius,
+                                                   coords.data_ptr(), ctx.mode, dout.data_ptr(),
+                                                   dcoords.data_ptr() if need_co else None,
+                                                   _stream(coords)), "lookup_bwd")
         # no gradient tensor for the anchor: the build node runs once every lookup of the pass has, whatever they return
         return None, dcoords, None, None, None
 
@@ -314,7 +376,11 @@ class _LookupConv(torch.autograd.Function):
             dweight = torch.einsum("bon,bkn->ok", dpre.reshape(B, Cout, -1), x.reshape(B, x.shape[1], -1)).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             dbias = dpre.sum(dim=(0, 2, 3))
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and pyr.deferred:
+            # W^T d(pre) straight in the record's layout (B, N, Cin): no transposition pass
+            rec = torch.einsum("ok,bon->bnk", w2, dpre.reshape(B, Cout, -1)).contiguous()
+            pyr.add_record(_lib.MODE_CANONICAL, blk.radius, coords, rec)
+        elif ctx.needs_input_grad[0]:
             dx = torch.einsum("ok,bon->bkn", w2, dpre.reshape(B, Cout, -1)).reshape(B, -1, pyr.H, pyr.W).contiguous()
             with _guard(coords):
                 pyr.grad_buffer()
@@ -345,11 +411,20 @@ class CorrBlock:
     half the memory (1080p: 2.8 instead of 5.7 GB), half the build's store traffic and half the line traffic
     of every lookup, at the price of the element rounding (bf16 2^-9, fp16 2^-12 relative; fp16 overflows
     beyond +-65504) -- the <= 1e-2 class of the north star's bf16 option.  Lookups return float32 either way;
-    gradients w.r.t. the features work as usual, the gradient w.r.t. coords needs "fp32"."""
+    gradients w.r.t. the features work as usual, the gradient w.r.t. coords needs "fp32".
 
-    def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32", volume_dtype="fp32"):
+    backward (keyword, not in the reference): how the lookups' gradients reach the features.  "deferred": every
+    lookup's backward pass only records (coords, d(out)); when autograd reaches the build, one kernel makes each
+    query's folded level-0 gradient row in LDS from all records (raftcorr_build_bwd_deferred) -- nothing dense is
+    zero-filled or read-modified-written per lookup.  "accumulate": the lookups add into one dense gradient pyramid
+    (raftcorr_lookup_bwd) that is folded once (raftcorr_build_bwd); needed for more than 4 levels or maps beyond
+    ~190 x 190.  "auto" (default): deferred where the shape allows.  Both are bit-reproducible."""
+
+    def __init__(self, fmap1, fmap2, num_levels=2, radius=4, precision="fp32", volume_dtype="fp32", backward="auto"):
         self.num_levels = num_levels
         self.radius = radius
+        if backward not in ("auto", "deferred", "accumulate"):
+            raise RuntimeError("CorrBlock: backward must be 'auto', 'deferred' or 'accumulate'")
         if precision not in _lib.PRECISIONS:
             raise RuntimeError(f"CorrBlock: precision must be one of {sorted(_lib.PRECISIONS)}; got {precision!r}")
         if volume_dtype not in _lib.VOLUMES:
@@ -372,6 +447,11 @@ class CorrBlock:
             # the reference fails in F.avg_pool2d ("Output size is too small"), core/corr.py:26
             raise RuntimeError(f"CorrBlock: a {H} x {W} map has no level {num_levels - 1}: output size is too small")
         self._pyr = _Pyramid(B, H, W, num_levels, fmap1.device, volume_dtype)
+        if backward != "accumulate" and num_levels <= 4 and radius <= 7:
+            self._pyr.set_deferred(radius)
+        if backward == "deferred" and not self._pyr.deferred:
+            raise RuntimeError(f"CorrBlock: the deferred backward does not take a {H} x {W} map with {num_levels} levels, "
+                               f"radius {radius}")
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
             flat, self._anchor = _BuildPyramid.apply(fmap1, fmap2, self._pyr, precision)
             self._pyr.flat = flat.detach()

@@ -262,6 +262,54 @@ int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int
                             workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
 }
 
+int64_t raftcorr_build_bwd_deferred_workspace_bytes(int B, int D, int H, int W)
+{
+    if (B < 1 || D < 1 || H < 1 || W < 1) return 0;
+    return (int64_t)build_bwd_deferred_workspace_bytes(B, D, H, W);
+}
+
+int raftcorr_build_bwd_deferred_supported(int H, int W, int num_levels, int radius)
+{
+    return build_bwd_deferred_supported(H, W, num_levels, radius) ? 1 : 0;
+}
+
+int raftcorr_lookup_bwd_record(const float* dout, int B, int H, int W, int channels, float* record, void* stream)
+{
+    int rc = check_dims("lookup_bwd_record", B, H, W);
+    if (rc) return rc;
+    if (!dout || !record) return fail(RAFTCORR_EINVAL, "lookup_bwd_record: null pointer");
+    if (channels < 1 || channels > 65535 * 256) return fail(RAFTCORR_EINVAL, "lookup_bwd_record: channels = %d", channels);
+    return launch_lookup_bwd_record(dout, B, H * W, channels, record, (hipStream_t)stream);
+}
+
+int raftcorr_build_bwd_deferred(const float* fmap1, const float* fmap2, int B, int D, int H, int W, int num_levels,
+                                int radius, int mode, int n_lookups, const float* const* coords,
+                                const float* const* records, float* const* dlevels, float* dfmap1, float* dfmap2,
+                                void* workspace, int64_t workspace_bytes, void* stream)
+{
+    int rc = check_dims("build_bwd_deferred", B, H, W);
+    if (rc) return rc;
+    if (!fmap1 || !fmap2 || !dfmap1 || !dfmap2) return fail(RAFTCORR_EINVAL, "build_bwd_deferred: null pointer");
+    if (D < 1) return fail(RAFTCORR_EINVAL, "build_bwd_deferred: D = %d", D);
+    if (mode != RAFTCORR_MODE_FORK && mode != RAFTCORR_MODE_CANONICAL)
+        return fail(RAFTCORR_EINVAL, "build_bwd_deferred: mode = %d", mode);
+    if (n_lookups < 0 || (n_lookups > 0 && (!coords || !records)))
+        return fail(RAFTCORR_EINVAL, "build_bwd_deferred: %d lookups, null coords/records", n_lookups);
+    for (int k = 0; k < n_lookups; ++k)
+        if (!coords[k] || !records[k] || ((uintptr_t)records[k] & 3)) return fail(RAFTCORR_EINVAL, "build_bwd_deferred: lookup %d: null pointer", k);
+    if (!build_bwd_deferred_supported(H, W, num_levels, radius))
+        return fail(RAFTCORR_EUNSUPPORTED, "build_bwd_deferred: %d x %d, %d levels, radius %d is not supported "
+                    "(raftcorr_build_bwd_deferred_supported); use raftcorr_lookup_bwd + raftcorr_build_bwd", H, W, num_levels, radius);
+    LevelSet dlv;
+    if (dlevels) {
+        rc = make_levels("build_bwd_deferred", dlevels, H, W, num_levels, dlv);
+        if (rc) return rc;
+    }
+    return launch_build_bwd_deferred(fmap1, fmap2, B, D, H, W, num_levels, radius, mode, n_lookups, coords, records,
+                                     dlevels ? &dlv : nullptr, dfmap1, dfmap2, workspace,
+                                     workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
+}
+
 static int alt_level_check(const char* who, int B, int N, int H1, int W1, int H2, int W2, int C, int r)
 {
     int rc = check_dims(who, B, H1, W1);

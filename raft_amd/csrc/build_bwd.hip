@@ -656,13 +656,20 @@ static unsigned grid_for(size_t total, unsigned cap)
     return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
-int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
-                     const LevelSet& dlv, float* df1, float* df2, void* workspace, size_t workspace_bytes,
-                     hipStream_t s)
+// forward declarations (bwd_deferred.hip)
+int launch_splat_fold(int B, int H, int W, int L, int r, int mode, int D, int K, const float* const* coords,
+                      const float* const* records, float* d0, int accumulate, float* wgmax, unsigned* n_wg, hipStream_t s);
+
+size_t build_bwd_deferred_workspace_bytes(int B, int D, int H, int W)
 {
-    if (!workspace || workspace_bytes < build_bwd_workspace_bytes(B, D, H, W))
-        return fail(RAFTCORR_EINVAL, "build_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes,
-                    build_bwd_workspace_bytes(B, D, H, W));
+    // the plain backward's workspace + the folded level-0 gradient [B * N][S0] behind it (256-byte aligned)
+    const size_t base = (build_bwd_workspace_bytes(B, D, H, W) + 255) / 256 * 256;
+    return base + (size_t)B * H * W * (size_t)level_geom(H, W, 0).slab * sizeof(float);
+}
+
+// classic fold of a dense gradient pyramid into its level 0 (in place); per-workgroup maxima -> wgmax[0 .. *n_wg)
+static int fold_stage(int B, int D, int H, int W, int L, const LevelSet& dlv, float* wgmax, unsigned* n_wg, hipStream_t s)
+{
     const int N = H * W;
     const size_t BN = (size_t)B * N;
     int rc;
@@ -675,11 +682,6 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
         rc = check_launch("corr_unpool_add_kernel");
         if (rc) return rc;
     }
-    // range pass for the fp16x2 contractions: |F1|, |F2| here, |folded gradient| by the fold kernel itself
-    float* maxima = (float*)((char*)workspace + build_bwd_workspace_bytes(B, D, H, W)) - (512 + FOLD_MAX_GRID);   // [3][128]
-    float* wgmax = maxima + 512;                             // [FOLD_MAX_GRID]
-    rc = launch_maxabs(f1, f2, (size_t)B * D * N, maxima, s);
-    if (rc) return rc;
     FoldArgs f;
     f.wgmax = wgmax;
     const int Lf = L < 4 ? L : 4;
@@ -695,9 +697,22 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
     const unsigned fold_grid = vec ? grid_for(BN * S0 / 4, FOLD_MAX_GRID) : grid_for(BN * S0, 16384);
     if (vec) hipLaunchKernelGGL(corr_fold_levels_kernel, dim3(fold_grid), dim3(256), 0, s, f);
     else     hipLaunchKernelGGL(corr_fold_levels_scalar_kernel, dim3(fold_grid), dim3(256), 0, s, f);
-    rc = check_launch("corr_fold_levels_kernel");
+    *n_wg = fold_grid;
+    return check_launch("corr_fold_levels_kernel");
+}
+
+// the two contractions on the folded level-0 gradient d0 [B * N][S0]; maxima: [3][128] (|F1|, |F2| filled here,
+// |d0| reduced here from wgmax[0 .. n_wg))
+static int contract_stage(const float* f1, const float* f2, int B, int D, int H, int W, const float* d0,
+                          float* df1, float* df2, void* workspace, float* maxima, const float* wgmax, unsigned n_wg,
+                          hipStream_t s)
+{
+    const int N = H * W;
+    const LevelGeom g0 = level_geom(H, W, 0);
+    const size_t S0 = (size_t)g0.slab;
+    int rc = launch_maxabs(f1, f2, (size_t)B * D * N, maxima, s);
     if (rc) return rc;
-    rc = launch_maxabs1(wgmax, fold_grid, maxima + 256, s);
+    rc = launch_maxabs1(wgmax, n_wg, maxima + 256, s);
     if (rc) return rc;
 
     float* f2v = (float*)workspace;                 // [B][D][S0]
@@ -710,22 +725,71 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
 
     GemmArgs a = {};
     // dF1[d][q] = sum_p F2v[d][p] * dC0[q][p]      (B operand: k = p contiguous)
-    a.A = f2v; a.B = dlv.ptr[0]; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
+    a.A = f2v; a.B = d0; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
     a.lda = (int)S0; a.ldb = (int)S0; a.ldc = N;
     a.sA = (size_t)D * S0; a.sB = (size_t)N * S0; a.sC = (size_t)D * N;
     a.maxA = maxima + 128; a.maxB = maxima + 256;
     rc = run_gemm<true>(a, B, planes, "gemm_f32_kernel<dF1>", s);
     if (rc) return rc;
     // dF2v[d][p] = sum_q F1[d][q] * dC0[q][p]      (B operand: n = p contiguous)
-    a.A = f1; a.B = dlv.ptr[0]; a.C = df2v; a.M = D; a.N = (int)S0; a.K = N;
+    a.A = f1; a.B = d0; a.C = df2v; a.M = D; a.N = (int)S0; a.K = N;
     a.lda = N; a.ldb = (int)S0; a.ldc = (int)S0;
     a.sA = (size_t)D * N; a.sB = (size_t)N * S0; a.sC = (size_t)D * S0;
     a.maxA = maxima;
     rc = run_gemm<false>(a, B, planes, "gemm_f32_kernel<dF2>", s);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_cols_scatter_back_kernel, dim3(grid_for((size_t)B * D * N, 16384)), dim3(256), 0, s,
-                       df2v, df2, B * D, H, W, dlv.g[0]);
+                       df2v, df2, B * D, H, W, g0);
     return check_launch("corr_cols_scatter_back_kernel");
+}
+
+int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
+                     const LevelSet& dlv, float* df1, float* df2, void* workspace, size_t workspace_bytes,
+                     hipStream_t s)
+{
+    if (!workspace || workspace_bytes < build_bwd_workspace_bytes(B, D, H, W))
+        return fail(RAFTCORR_EINVAL, "build_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                    build_bwd_workspace_bytes(B, D, H, W));
+    // range pass for the fp16x2 contractions: |F1|, |F2| by a small pass, |folded gradient| by the fold kernel itself
+    float* maxima = (float*)((char*)workspace + build_bwd_workspace_bytes(B, D, H, W)) - (512 + FOLD_MAX_GRID);   // [3][128]
+    float* wgmax = maxima + 512;                             // [FOLD_MAX_GRID]
+    unsigned n_wg = 0;
+    int rc = fold_stage(B, D, H, W, L, dlv, wgmax, &n_wg, s);
+    if (rc) return rc;
+    return contract_stage(f1, f2, B, D, H, W, dlv.ptr[0], df1, df2, workspace, maxima, wgmax, n_wg, s);
+}
+
+// Deferred form: the lookups' gradients arrive as K recorded (coords, d(out)) pairs instead of (or, dlv != nullptr, on
+// top of) a dense gradient pyramid; see bwd_deferred.hip.
+int launch_build_bwd_deferred(const float* f1, const float* f2, int B, int D, int H, int W, int L, int r, int mode,
+                              int K, const float* const* coords, const float* const* records, const LevelSet* dlv,
+                              float* df1, float* df2, void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    const size_t base = (build_bwd_workspace_bytes(B, D, H, W) + 255) / 256 * 256;
+    const size_t need = dlv ? build_bwd_workspace_bytes(B, D, H, W) : build_bwd_deferred_workspace_bytes(B, D, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(RAFTCORR_EINVAL, "build_bwd_deferred: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    if (((uintptr_t)workspace & 15) != 0) return fail(RAFTCORR_EINVAL, "build_bwd_deferred: workspace must be 16-byte aligned");
+    float* maxima = (float*)((char*)workspace + build_bwd_workspace_bytes(B, D, H, W)) - (512 + FOLD_MAX_GRID);
+    float* wgmax = maxima + 512;
+    unsigned n_wg = 0;
+    float* d0;
+    int rc;
+    if (dlv) {                                               // a dense pyramid gradient as well: fold it first, add the records
+        if ((uintptr_t)dlv->ptr[0] % 16 != 0) return fail(RAFTCORR_EINVAL, "build_bwd_deferred: dlevels[0] must be 16-byte aligned");
+        rc = fold_stage(B, D, H, W, L, *dlv, wgmax, &n_wg, s);
+        if (rc) return rc;
+        d0 = dlv->ptr[0];
+    } else {
+        d0 = (float*)((char*)workspace + base);
+    }
+    if (K > 0) {
+        rc = launch_splat_fold(B, H, W, L, r, mode, D, K, coords, records, d0, dlv ? 1 : 0, wgmax, &n_wg, s);
+        if (rc) return rc;
+    } else if (!dlv) {
+        return fail(RAFTCORR_EINVAL, "build_bwd_deferred: neither records nor a pyramid gradient given");
+    }
+    return contract_stage(f1, f2, B, D, H, W, d0, df1, df2, workspace, maxima, wgmax, n_wg, s);
 }
 
 }  // namespace raftcorr

@@ -36,6 +36,12 @@ int launch_lookup_conv1x1(const LevelSet& lv, int B, int H, int W, int L, int r,
 int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int W, int L,
                      const LevelSet& dlv, float* df1, float* df2, void* workspace, size_t workspace_bytes,
                      hipStream_t s);
+size_t build_bwd_deferred_workspace_bytes(int B, int D, int H, int W);
+bool build_bwd_deferred_supported(int H, int W, int L, int r);
+int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec, hipStream_t s);
+int launch_build_bwd_deferred(const float* f1, const float* f2, int B, int D, int H, int W, int L, int r, int mode,
+                              int K, const float* const* coords, const float* const* records, const LevelSet* dlv,
+                              float* df1, float* df2, void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, float* corr,
                          int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
 int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,

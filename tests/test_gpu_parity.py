@@ -650,6 +650,89 @@ def test_all_pairs_backward_is_bit_reproducible(dev):
             assert rel_err(grads[0][0], c1.grad.numpy()) <= GTOL and rel_err(grads[0][1], c2.grad.numpy()) <= GTOL
 
 
+@pytest.mark.parametrize("case", [(2, 32, 40, 72, 4, 4, 12), (1, 16, 13, 19, 2, 3, 3), (1, 24, 21, 34, 3, 5, 20),
+                                  (3, 8, 9, 21, 1, 4, 2), (1, 16, 24, 40, 4, 7, 11), (1, 8, 16, 24, 4, 0, 2)])
+def test_deferred_backward_matches_accumulate_and_oracle(case, dev):
+    """raftcorr_build_bwd_deferred (lookups recorded, one kernel makes the folded level-0 gradient in LDS) against
+    raftcorr_lookup_bwd + raftcorr_build_bwd (dense gradient pyramid, folded once) and against the oracle's autograd:
+    both coordinate conventions, odd sizes, every radius class (3, 4 specialised; 0, 5, 7 generic), more lookups than
+    one launch stages (16), coordinates outside the map; the same bits on a second run."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    B, D, H, W, L, r, nl = case
+    rs = np.random.RandomState(sum(case))
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].astype(np.float32)
+    rd2 = (2 * r + 1) ** 2
+    for mode in ("canon", "fork"):
+        cons = [(base + (0.5 + k) * rs.randn(B, 2, H, W)).astype(np.float32) for k in range(nl)]
+        cons[0][0, :, 0, 0] = [-50.0, 1e9]
+        if mode == "fork":
+            cons = [np.ascontiguousarray(c.transpose(0, 2, 3, 1).reshape(B, H * W, 2)) for c in cons]
+        gns = [rs.randn(*((B, H * W, L * rd2) if mode == "fork" else (B, L * rd2, H, W))).astype(np.float32) for _ in range(nl)]
+
+        def run(make, device):
+            f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+            f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+            cb = make(f1, f2)
+            torch.autograd.backward([cb(torch.from_numpy(c).to(device)) for c in cons],
+                                    [torch.from_numpy(g).to(device) for g in gns])
+            return f1.grad.cpu().numpy(), f2.grad.cpu().numpy()
+
+        d1, d2 = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r, backward="deferred"), dev)
+        a1, a2 = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r, backward="accumulate"), dev)
+        o1, o2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu")
+        e = (max(rel_err_by_item(d1, o1)), max(rel_err_by_item(d2, o2)), rel_err(d1, a1), rel_err(d2, a2))
+        log_errors(f"deferred_{mode}_{'_'.join(str(c) for c in case)}", dfmap1=e[0], dfmap2=e[1], vs_accumulate1=e[2], vs_accumulate2=e[3])
+        assert e[0] <= GTOL and e[1] <= GTOL, (mode, e)
+        assert e[2] <= 2e-6 and e[3] <= 2e-6, (mode, e)                 # the two routes differ by summation order only
+        again = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r, backward="deferred"), dev)
+        assert np.array_equal(d1, again[0]) and np.array_equal(d2, again[1])
+
+
+def test_deferred_backward_with_pyramid_gradient_and_both_conventions(dev):
+    """One backward pass that reaches the build node three ways: lookups in canonical mode (recorded), a lookup in fork
+    mode (a deferred launch serves one convention: it goes through the dense accumulator) and a gradient on the pyramid
+    tensors themselves (corr_pyramid, dense): raftcorr_build_bwd_deferred folds the dense part and adds the records."""
+    from raft_amd import CorrBlock
+    from oracle import corr_oracle as O
+    rs = np.random.RandomState(77)
+    B, D, H, W, L, r = 2, 16, 18, 26, 3, 4
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    c4 = [(rs.rand(B, 2, H, W) * [[[W]], [[H]]]).astype(np.float32) for _ in range(2)]
+    c3 = (rs.rand(B, H * W, 2) * [W, H]).astype(np.float32)
+    g4 = [rs.randn(B, L * 81, H, W).astype(np.float32) for _ in range(2)]
+    g3 = rs.randn(B, H * W, L * 81).astype(np.float32)
+    wl = [rs.randn(B * H * W, 1, H >> l, W >> l).astype(np.float32) for l in range(L)]
+
+    def run(make, device):
+        f1 = torch.from_numpy(f1n).to(device).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(device).requires_grad_(True)
+        cb = make(f1, f2)
+        outs = [cb(torch.from_numpy(c).to(device)) for c in c4] + [cb(torch.from_numpy(c3).to(device))] + list(cb.corr_pyramid)
+        gr = [torch.from_numpy(g).to(device) for g in g4 + [g3] + wl]
+        torch.autograd.backward(outs, gr)
+        return f1.grad.cpu().numpy(), f2.grad.cpu().numpy()
+
+    d1, d2 = run(lambda a, b: CorrBlock(a, b, num_levels=L, radius=r), dev)
+    o1, o2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu")
+    assert rel_err(d1, o1) <= GTOL and rel_err(d2, o2) <= GTOL
+
+
+def test_lookup_bwd_record_is_a_transposition(dev):
+    """raftcorr_lookup_bwd_record through the C ABI: (B, C, H, W) -> (B, H*W, C), bit for bit, ragged query blocks,
+    channel counts below and above the whole-row tile (384)."""
+    from raft_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for (B, C, H, W) in ((2, 324, 13, 19), (1, 900, 9, 11), (3, 81, 50, 90), (1, 1, 1, 1)):
+        x = torch.randn(B, C, H, W, device=dev)
+        rec = torch.full((B, H * W, C), float("nan"), device=dev)
+        _lib.check(lib.raftcorr_lookup_bwd_record(x.data_ptr(), B, H, W, C, rec.data_ptr(), st), "lookup_bwd_record")
+        assert torch.equal(rec, x.reshape(B, C, H * W).permute(0, 2, 1))
+
+
 def test_on_the_fly_backward_is_bit_reproducible(dev):
     """raftcorr_alt_lookup_bwd has one writer per gradient element and a fixed summation order (no atomics):
     two runs on the same inputs must agree bit for bit, also with incoherent flow (long partner lists, split
