@@ -300,6 +300,21 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
                             float* dfmap1, float* const* dfmap2_levels, int accumulate,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* raftcorr_alt_lookup_bwd with the query tiles formed by WINDOW position, the backward counterpart of
+ * raftcorr_alt_lookup_fwd_sorted (no reference line: the reference's kernel works pixel by pixel).  Same arguments and
+ * results as raftcorr_alt_lookup_bwd (to the order of the fp32 sums), except packed1: the FORWARD pass' packed copy of
+ * fmap1 (raftcorr_alt_pack) instead of the tile-major one -- the tile-major partner images are gathered per call for
+ * the query groups.  The groups are a function of the coordinates alone (buckets by the 8x8 level-0 cell of the window
+ * centre, members in query order, no atomics), so the results are bit-reproducible like the pixel-tile call's.  A pixel
+ * tile's cost grows with the disagreement of its 64 flow vectors; a group's does not.  Four more small launches per
+ * call: choose it when the flow is rough.  workspace: raftcorr_alt_lookup_bwd_sorted_workspace_bytes(...). */
+int64_t raftcorr_alt_lookup_bwd_sorted_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius);
+int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles2_levels, const float* scales,
+                                   int B, int H, int W, int C, int num_levels, int radius,
+                                   const float* coords, const float* dout,
+                                   float* dfmap1, float* const* dfmap2_levels, int accumulate,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Set-up and tear-down of one frame pair of the on-the-fly block, one host call each (what core/corr.py:64-73 does in
  * its constructor -- the avg_pool2d chain -- plus the packed copies the kernels above read; and its adjoint).
  *   raftcorr_alt_prepare       = raftcorr_alt_scales + the fmap2 pyramid (avg_pool2d(., 2, stride=2) chain, levels

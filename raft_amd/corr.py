@@ -682,10 +682,17 @@ class _AltLookup(torch.autograd.Function):
         acc, first = blk._gstate.buffers()
         work = blk._bwd_workspace()
         with _guard(coords):
-            _lib.check(lib.raftcorr_alt_lookup_bwd(blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
-                                                   blk.radius, coords.data_ptr(), dout.data_ptr(),
-                                                   acc[0].data_ptr(), blk._gstate.ptrs, 0 if first else 1,
-                                                   work.data_ptr(), work.numel(), _stream(coords)), "alt_lookup_bwd")
+            if blk.tiles == "window":                            # query groups by window position (deterministic lists)
+                _lib.check(lib.raftcorr_alt_lookup_bwd_sorted(blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W,
+                                                              C, L, blk.radius, coords.data_ptr(), dout.data_ptr(),
+                                                              acc[0].data_ptr(), blk._gstate.ptrs, 0 if first else 1,
+                                                              work.data_ptr(), work.numel(), _stream(coords)),
+                           "alt_lookup_bwd_sorted")
+            else:
+                _lib.check(lib.raftcorr_alt_lookup_bwd(blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
+                                                       blk.radius, coords.data_ptr(), dout.data_ptr(),
+                                                       acc[0].data_ptr(), blk._gstate.ptrs, 0 if first else 1,
+                                                       work.data_ptr(), work.numel(), _stream(coords)), "alt_lookup_bwd")
         # coords gradient: the reference kernel never writes it (correlation_kernel.cu:307)
         # (no gradient tensor for the anchor: _AltFeatures.backward runs once every lookup of the pass has)
         return None, None, None
@@ -782,7 +789,9 @@ class AlternateCorrBlock:
     def _bwd_workspace(self):
         if self._work is None:
             B, C, H, W = self._shape
-            nbytes = _lib.load().raftcorr_alt_lookup_bwd_workspace_bytes(B, H, W, C, self.num_levels, self.radius)
+            fn = _lib.load().raftcorr_alt_lookup_bwd_sorted_workspace_bytes if self.tiles == "window" else \
+                _lib.load().raftcorr_alt_lookup_bwd_workspace_bytes
+            nbytes = fn(B, H, W, C, self.num_levels, self.radius)
             self._work = torch.empty(nbytes, dtype=torch.uint8, device=self._p1.device)
         return self._work
 

@@ -65,6 +65,13 @@ struct AltBwdArgs {
     int gw;                                       // channels per workgroup: CG or GW (see make_plan)
     int accumulate;                               // != 0: df1 / df2 += (same single writer per element), else overwritten
     float sqrt_c;
+    // window mode (qlist != nullptr): a "query tile" is a GROUP of 64 queries whose level-0 windows start in the same
+    // 8x8 cell (alt_wfill_kernel: groups in bucket order, members in query order -- a function of the coordinates
+    // alone); qtiles = group slots per batch item, ngr[b] of them in use.  f1t then is the tile-major copy of fmap1
+    // gathered for the groups, dg the groups' d(out) tiles [B][L][qtiles][rd*rd][64].
+    const int* qlist;                             // [B][qtiles][64] query pixel indices, -1 = empty slot
+    const int* ngr;                               // [B]
+    float* dg;
 };
 
 struct BwdSh {
@@ -127,15 +134,140 @@ void alt_pack_tiles_kernel(PackSet ps)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Window mode: query groups by window position, deterministic.  The queries are dealt into buckets by the 8x8 cell of
+// level-0 targets that holds their window centre (one ring of cells around the map takes the centres outside it);
+// every 64 queries of a bucket, IN QUERY ORDER, form a group, groups are numbered in bucket order.  Three small
+// launches: count (one wave per bucket scans the coordinates), scan (groups per bucket -> first group), fill (the same
+// scan as the count, ordered compaction by ballot + popcount).  No atomics: the lists depend on the coordinates only,
+// so the backward pass stays bit-reproducible.  Under smooth flow a bucket is a pixel tile; under per-pixel noise the
+// box of a group stays (8 + 2r + 2)^2 at level 0 where a pixel tile's box grows with the noise.
+struct WSortArgs {
+    const float* coords;                          // (B, 2, H, W)
+    int* cnt;                                     // [B][nb][nch] queries of chunk ch in the bucket; after the scan: the
+                                                  // bucket's queries in the chunks before ch
+    int* toff;                                    // [B][nb] first group of the bucket
+    int* ngr;                                     // [B] groups in use
+    int* qlist;                                   // [B][gmax][64]
+    int N, nbx, nby, nb, nch, gmax;
+};
+
+constexpr int WCHUNK = 1024;                      // queries per (bucket, chunk) wave
+
+__device__ __forceinline__ int wbucket_key(const WSortArgs& p, float x, float y)
+{
+    int x0, y0;
+    float f;
+    split_coord(x, x0, f);
+    split_coord(y, y0, f);
+    return (min(max(y0 >> 3, -1), p.nby - 2) + 1) * p.nbx + min(max(x0 >> 3, -1), p.nbx - 2) + 1;
+}
+
+// One wave per (bucket, chunk of WCHUNK consecutive queries).  FILL = false: cnt[b][bucket][chunk]; FILL = true: the
+// chunk's queries of the bucket -> qlist behind those of the earlier chunks (ordered compaction by ballot + popcount),
+// the bucket's last group padded with -1 by its last chunk.  grid (nb, nch, B), block 64
+template <bool FILL>
+__global__ __launch_bounds__(64)
+void alt_wbucket_kernel(WSortArgs p)
+{
+    const int bucket = blockIdx.x, ch = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const float* __restrict__ cx = p.coords + (size_t)b * 2 * p.N;
+    const int slot = (b * p.nb + bucket) * p.nch + ch;
+    int n = FILL ? p.cnt[slot] : 0;               // wave-uniform: position inside the bucket / count
+    int* __restrict__ list = FILL ? p.qlist + ((size_t)b * p.gmax + p.toff[b * p.nb + bucket]) * 64 : nullptr;
+    const int qa = ch * WCHUNK;
+    float x[WCHUNK / 64], y[WCHUNK / 64];
+#pragma unroll
+    for (int u = 0; u < WCHUNK / 64; ++u) {       // all loads of the chunk in flight
+        const int q = min(qa + u * 64 + lane, p.N - 1);
+        x[u] = cx[q]; y[u] = cx[p.N + q];
+    }
+#pragma unroll
+    for (int u = 0; u < WCHUNK / 64; ++u) {
+        const int q = qa + u * 64 + lane;
+        const bool mine = q < p.N && wbucket_key(p, x[u], y[u]) == bucket;
+        const unsigned long long m = __ballot(mine);
+        if (FILL && mine) list[n + __popcll(m & ((1ull << lane) - 1))] = q;
+        n += __popcll(m);
+    }
+    if (!FILL) { if (lane == 0) p.cnt[slot] = n; return; }
+    if (ch == p.nch - 1 && (n & 63) && lane >= (n & 63)) list[(n & ~63) + lane] = -1;
+}
+
+// groups per bucket -> first group of every bucket, groups in use; cnt becomes the exclusive prefix over a bucket's
+// chunks.  grid (B), block 1024
+__global__ __launch_bounds__(1024)
+void alt_wscan_kernel(WSortArgs p)
+{
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* __restrict__ cnt = p.cnt + (size_t)b * p.nb * p.nch;
+    int* __restrict__ off = p.toff + b * p.nb;
+    const int per = (p.nb + 1023) / 1024, i0 = min(tid * per, p.nb), i1 = min(i0 + per, p.nb);
+    int local = 0;
+    for (int i = i0; i < i1; ++i) {
+        int tot = 0;
+        for (int c = 0; c < p.nch; ++c) { const int v = cnt[i * p.nch + c]; cnt[i * p.nch + c] = tot; tot += v; }
+        off[i] = (tot + 63) >> 6;                            // groups of the bucket, replaced by its first group below
+        local += off[i];
+    }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - local, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; run += w < wave ? v : 0; total += v; }
+    for (int i = i0; i < i1; ++i) { const int groups = off[i]; off[i] = run; run += groups; }
+    if (tid == 0) p.ngr[b] = total;
+}
+
+// tile-major copy of fmap1 for the groups (the partner images of the d(fmap2) role), gathered from the forward
+// pass' packed copy [pixel][Cp/32][hi: 4 slots of 8 channels | lo: 4 slots] (alt_fwd16.hip; same scaling).
+// grid (qtiles, Cp / 32, B), block 256
+__global__ __launch_bounds__(256)
+void alt_wgather_f1_kernel(const uint4* __restrict__ f1p, uint4* __restrict__ f1g, const int* __restrict__ qlist,
+                           const int* __restrict__ ngr, int qtiles, int Cp, size_t P)
+{
+    __shared__ uint4 lines[TQ * 8];               // [query][slot]: the queries' 128-byte lines of this channel chunk
+    const int g = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, nkc = Cp / 32;
+    if (g >= ngr[b]) return;
+    const int* __restrict__ ql = qlist + ((size_t)b * qtiles + g) * TQ;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i, pix = ql[e >> 3];
+        const uint4 v = f1p[(((size_t)b * P + max(pix, 0)) * nkc + chunk) * 8 + (e & 7)];
+        lines[e] = pix >= 0 ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const unsigned short* h = (const unsigned short*)lines;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int o = tid + 256 * i, c = o >> 4, sl = o & 15, piece = sl >> 3, q0 = (sl & 7) * 8;
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h[((q0 + j) * 8 + piece * 4 + (c >> 3)) * 8 + (c & 7)];
+        uint4 w;
+        w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
+        w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+        f1g[(((size_t)b * qtiles + g) * Cp + chunk * 32 + c) * 16 + sl] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The two small passes in front of the main kernel, in one launch (they do not depend on each other):
 //   workgroups [0, B * L * qtiles): per (batch, level, query tile) the 64 windows (origin + fractions) and their bounding box;
 //   the DMAXP workgroups after them: partial maxima of |d(out)| (n floats), the range of the G images.
 // block 64
-__global__ __launch_bounds__(64)
-void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)
+__global__ __launch_bounds__(256)
+void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)   // block 64 (pixel tiles) or 256 (window mode)
 {
     __shared__ TileQ sh;
     if ((int)blockIdx.x >= nwin) {
+        if (threadIdx.x >= 64) return;                       // (window mode launches 256 threads)
         const int j = blockIdx.x - nwin, lane = threadIdx.x;
         const float* __restrict__ x = p.dout;
         float m = 0.f;
@@ -161,11 +293,35 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)
         return;
     }
     const int tile = blockIdx.x % p.qtiles, bl = blockIdx.x / p.qtiles;
+    const int q = threadIdx.x;
     Tile16 t;
     t.l = bl % p.L; t.b = bl / p.L;
-    t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
-    tile_level_setup(p, sh, t);
-    const int q = threadIdx.x;
+    if (p.qlist) {                                           // window mode: the tile is a group of the list
+        if (tile >= p.ngr[t.b]) {                            // slot not in use: an empty box keeps it out of every walk
+            if (q == 0) p.boxes[blockIdx.x] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+            return;
+        }
+        t.ty0 = t.tx0 = 0;
+        tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.qtiles + tile) * TQ);
+        // the group's d(out) tile [rd*rd][64], gathered once: the main kernel then fetches it with contiguous loads.
+        // Four waves, each every fourth batch of 16 channels.
+        const int rd2 = (2 * p.r + 1) * (2 * p.r + 1), qq = q & 63, pix = sh.qpix[qq];
+        const size_t P = (size_t)p.H * p.W;
+        const float* __restrict__ src = p.dout + ((size_t)t.b * p.L + t.l) * rd2 * P + max(pix, 0);
+        float* __restrict__ dst = p.dg + (size_t)blockIdx.x * rd2 * TQ + qq;
+        for (int c0 = 16 * (q >> 6); c0 < rd2; c0 += 16 * (blockDim.x >> 6)) {     // 16 loads in flight
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)min(c0 + j, rd2 - 1) * P];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (c0 + j < rd2) dst[(c0 + j) * TQ] = pix >= 0 ? v[j] : 0.f;
+        }
+        if (q >= 64) return;
+    } else {
+        t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
+        tile_level_setup(p, sh, t);
+    }
     p.wins[(size_t)blockIdx.x * TQ + q] = make_int4(sh.wx0[q], sh.wy0[q], __float_as_int(sh.fx[q]), __float_as_int(sh.fy[q]));
     if (q == 0) p.boxes[blockIdx.x] = make_int4(sh.box[0], sh.box[1], sh.box[2], sh.box[3]);
 }
@@ -211,15 +367,30 @@ struct DTile {
     int4 win;
 };
 
+// where the d(out) window of query q of tile qt lives: channel ch at (base + ch * stride)[lane_off].  Pixel tiles read
+// d(out) itself (B, L*rd*rd, H, W); window mode reads the group's gathered tile [rd*rd][64] (alt_bwd_pre_kernel).
+__device__ __forceinline__ const float* dtile_source(const AltBwdArgs& p, int b, int l, int qt, int rd2, int q,
+                                                     size_t& stride, unsigned& lane_off)
+{
+    if (p.qlist) {
+        stride = TQ; lane_off = (unsigned)q;
+        return p.dg + (((size_t)b * p.L + l) * p.qtiles + qt) * rd2 * TQ;
+    }
+    const size_t P = (size_t)p.H * p.W;
+    const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
+    stride = P;
+    lane_off = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;               // out-of-map queries: any address
+    return p.dout + ((size_t)b * p.L + l) * rd2 * P;
+}
+
 __device__ __forceinline__ void dtile_issue(const AltBwdArgs& p, DTile& d, int b, int l, int qt, int rd2, int wave)
 {
-    const size_t P = (size_t)p.H * p.W;
     const int q = threadIdx.x & 63;
-    const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
-    const unsigned pix = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;      // out-of-map queries: any address
-    const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P;         // wave-uniform: scalar base + lane offset
+    size_t stride;
+    unsigned lane_off;
+    const float* __restrict__ src = dtile_source(p, b, l, qt, rd2, q, stride, lane_off);   // wave-uniform base + lane offset
 #pragma unroll
-    for (int j = 0; j < 24; ++j) d.v[j] = (src + (size_t)min(wave + 4 * j, rd2 - 1) * P)[pix];
+    for (int j = 0; j < 24; ++j) d.v[j] = (src + (size_t)min(wave + 4 * j, rd2 - 1) * stride)[lane_off];
     d.win = p.wins[(((size_t)b * p.L + l) * p.qtiles + qt) * TQ + q];
 }
 
@@ -235,11 +406,10 @@ __device__ __forceinline__ void dtile_commit(const AltBwdArgs& p, const DTile& d
     // step, where hipcc has to wait for ALL vector-memory traffic before it can reuse the registers
     sh.wx0[q] = d.win.x; sh.wy0[q] = d.win.y; sh.fx[q] = __int_as_float(d.win.z); sh.fy[q] = __int_as_float(d.win.w);
     if (rd2 > 96) {
-        const size_t P = (size_t)p.H * p.W;
-        const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
-        const unsigned pix = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;
-        const float* __restrict__ src = p.dout + ((size_t)b * p.L + l) * rd2 * P;
-        for (int ch = 96 + wave; ch < rd2; ch += 4) D[ch * 64 + q] = (src + (size_t)ch * P)[pix];
+        size_t stride;
+        unsigned lane_off;
+        const float* __restrict__ src = dtile_source(p, b, l, qt, rd2, q, stride, lane_off);
+        for (int ch = 96 + wave; ch < rd2; ch += 4) D[ch * 64 + q] = (src + (size_t)ch * stride)[lane_off];
     }
 }
 
@@ -418,9 +588,23 @@ void alt_bwd_kernel(AltBwdArgs p)
     auto banded = [](int idx, int len) { return (idx & 7) * (len >> 3) + (idx >> 3); };
     if (wg < p.seg[0]) {
         // ---------------- d(fmap1): owner = query tile, partners = target tiles of every level ----------------
-        const int item = banded(wg, p.seg[0]);
-        if (item >= p.B * p.qtiles * p.ngroups) return;      // padding of the segment (whole workgroup)
-        const int g = item % p.ngroups, rest = item / p.ngroups, tile = rest % p.qtiles, b = rest / p.qtiles;
+        int g, tile, b;
+        if (p.qlist) {
+            // window mode: the segment holds pad8(qtiles * ngroups) ids per batch item, but only ngr[b] group slots are
+            // in use: the bands are eighths of THOSE (groups are in bucket order = bands of image rows)
+            const int perb = (p.qtiles * p.ngroups + 7) & ~7;
+            b = wg / perb;
+            const int wb = wg - b * perb, n_items = p.ngr[b] * p.ngroups, band = (n_items + 7) >> 3;
+            const int item = (wb & 7) * band + (wb >> 3);
+            if ((wb >> 3) >= band || item >= n_items) return;    // (whole workgroup)
+            g = item % p.ngroups; tile = item / p.ngroups;
+        } else {
+            const int item = banded(wg, p.seg[0]);
+            if (item >= p.B * p.qtiles * p.ngroups) return;  // padding of the segment (whole workgroup)
+            g = item % p.ngroups;
+            const int rest = item / p.ngroups;
+            tile = rest % p.qtiles; b = rest / p.qtiles;
+        }
         const int rows = min(p.gw, p.Cp - g * p.gw);             // channels of this workgroup (a multiple of 32)
         DTile dt;
         dtile_issue(p, dt, b, 0, tile, rd2, wave);
@@ -442,6 +626,16 @@ void alt_bwd_kernel(AltBwdArgs p)
         }
         const float unscale = ldexpf(1.0f, -(eg + e2));
         float* __restrict__ out = p.df1 + (size_t)b * P * p.C;
+        int opix[16];                                        // pixel of the query behind accumulator register i, -1 = none
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            if (p.qlist) opix[i] = p.qlist[((size_t)b * p.qtiles + tile) * TQ + q];
+            else {
+                const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
+                opix[i] = (gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
+            }
+        }
 #pragma unroll
         for (int hj = 0; hj < NH * (NCB / 2); ++hj) {
             const int h = hj / (NCB / 2), j = hj % (NCB / 2);
@@ -449,10 +643,8 @@ void alt_bwd_kernel(AltBwdArgs p)
             if (h * CG < rows && c < p.C) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
-                    if (gy < p.H && gx < p.W) {
-                        float* o = out + ((size_t)gy * p.W + gx) * p.C + c;
+                    if (opix[i] >= 0) {
+                        float* o = out + (size_t)opix[i] * p.C + c;
                         float v = (acc[h][j][i] * unscale) / p.sqrt_c;
                         if (p.accumulate) v += *o;
                         *o = v;
@@ -597,38 +789,59 @@ struct BwdPlan {
     size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
     size_t off_boxes, off_wins, off_partial, bytes;
     bool any_split;
+    // window mode
+    int nbx, nby, nb, nch;
+    size_t off_cnt, off_toff, off_ngr, off_qlist, off_dg, off_f1g;
 };
 
-BwdPlan make_plan(int B, int H, int W, int C, int L, int r)
+BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
 {
     BwdPlan pl = {};
     pl.Cp = (C + 31) / 32 * 32;
     pl.qtx = (W + QW - 1) / QW;
-    pl.qtiles = pl.qtx * ((H + QH - 1) / QH);
+    const int ptiles = pl.qtx * ((H + QH - 1) / QH);         // 8x8 pixel tiles
+    pl.qtiles = ptiles;
+    if (window) {
+        // buckets = 8x8 cells of level-0 targets + one ring; group slots: every bucket may end in a partly filled group
+        pl.nbx = ((W + 7) >> 3) + 2; pl.nby = ((H + 7) >> 3) + 2; pl.nb = pl.nbx * pl.nby;
+        pl.qtiles = (H * W + TQ - 1) / TQ + pl.nb;
+        pl.nch = (H * W + WCHUNK - 1) / WCHUNK;
+    }
     // Channels per workgroup.  GW: the G image of a step is built once and multiplied with two partner slices (half the
     // construction work, the kernel's bottleneck) -- when the query tiles alone fill the chip; with few tiles (KITTI at
     // B = 1: 120) twice as many workgroups with one slice each balance better (measured both ways at both sizes).
-    pl.gw = (long long)B * pl.qtiles >= 256 ? GW : CG;
+    pl.gw = (long long)B * ptiles >= 256 ? GW : CG;
     pl.ngroups = (pl.Cp + pl.gw - 1) / pl.gw;
     auto pad8 = [](long long n) { return (int)((n + 7) / 8 * 8); };
-    pl.seg[0] = pad8((long long)B * pl.qtiles * pl.ngroups);
+    pl.seg[0] = window ? B * pad8((long long)pl.qtiles * pl.ngroups) : pad8((long long)B * pl.qtiles * pl.ngroups);
     size_t pf = 0;
     for (int l = 0; l < L; ++l) {
         const int hl = H >> l, wl = W >> l;
         pl.ttiles[l] = ((wl + 7) / 8) * ((hl + 7) / 8);
         // query tiles that touch one target tile when the flow is smooth: ((8 + 2r + 2) * 2^l / 8 + 1)^2
         const long long side = (((long long)(8 + 2 * r + 2) << l) >> 3) + 1;
-        const long long est = std::min<long long>(pl.qtiles, side * side);
+        const long long est = std::min<long long>(ptiles, side * side);
         pl.nsplit[l] = (int)std::min<long long>(MAXSPLIT, std::max<long long>(1, (est + 11) / 12));
         if (l == 0) pl.nsplit[l] = 1;
         pl.seg[l + 1] = pl.seg[l] + pad8((long long)B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups);
         pl.poff[l] = pf;
         if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
     }
+    auto up = [](size_t n) { return (n + 255) / 256 * 256; };
     pl.off_boxes = DMAXP * sizeof(float);                    // in front: partial maxima of |dout|
-    pl.off_wins = (pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles + 255) / 256 * 256;
-    pl.off_partial = (pl.off_wins + sizeof(int4) * (size_t)B * L * pl.qtiles * TQ + 255) / 256 * 256;
-    pl.bytes = pl.off_partial + pf * sizeof(float);
+    pl.off_wins = up(pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles);
+    pl.off_partial = up(pl.off_wins + sizeof(int4) * (size_t)B * L * pl.qtiles * TQ);
+    size_t end = up(pl.off_partial + pf * sizeof(float));
+    if (window) {
+        const int rd2 = (2 * r + 1) * (2 * r + 1);
+        pl.off_cnt = end;    end = up(end + sizeof(int) * (size_t)B * pl.nb * pl.nch);
+        pl.off_toff = end;   end = up(end + sizeof(int) * (size_t)B * pl.nb);
+        pl.off_ngr = end;    end = up(end + sizeof(int) * (size_t)B);
+        pl.off_qlist = end;  end = up(end + sizeof(int) * (size_t)B * pl.qtiles * TQ);
+        pl.off_dg = end;     end = up(end + sizeof(float) * (size_t)B * L * pl.qtiles * rd2 * TQ);
+        pl.off_f1g = end;    end = up(end + (size_t)B * pl.qtiles * pl.Cp * 256);
+    }
+    pl.bytes = end;
     return pl;
 }
 
@@ -658,21 +871,26 @@ int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const f
     return launch_alt_pack_tiles_set(&fmap, &H, &W, &maxpart, &packed, 1, B, C, s);
 }
 
-size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r)
+size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window)
 {
-    return make_plan(B, H, W, C, L, r).bytes;
+    return make_plan(B, H, W, C, L, r, window).bytes;
 }
 
+// f1p_window != nullptr selects window mode: f1t is ignored, the tile-major partner images of fmap1 are gathered per
+// call for the query groups from the forward pass' packed copy f1p_window
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t s)
+                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window)
 {
     if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: radius %d > 7", r);
-    const BwdPlan pl = make_plan(B, H, W, C, L, r);
+    const bool window = f1p_window != nullptr;
+    const BwdPlan pl = make_plan(B, H, W, C, L, r, window);
     if (!workspace || workspace_bytes < pl.bytes)
         return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace of %zu bytes needed, %zu given", pl.bytes, workspace_bytes);
     if (((uintptr_t)workspace & 255) != 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace must be 256-byte aligned");
-    if ((long long)pl.seg[L] <= 0 || (size_t)B * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31))
+    if ((long long)pl.seg[L] <= 0 || (size_t)B * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31) ||
+        (window && ((size_t)H * W * (pl.Cp / 32) * 8 >= ((size_t)1 << 31) || pl.nb > 65535 || pl.nch > 65535 ||
+                    (size_t)B * L * pl.qtiles * (2 * r + 1) * (2 * r + 1) * TQ >= ((size_t)1 << 31))))
         return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
     AltBwdArgs a = {};
     a.f1t = (const uint4*)f1t;
@@ -691,9 +909,29 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     a.sqrt_c = sqrtf((float)C);
     a.accumulate = accumulate;
     const int rd2 = (2 * r + 1) * (2 * r + 1);
-    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3(B * L * pl.qtiles + DMAXP), dim3(64), 0, s, a, B * L * pl.qtiles,
+    int rc;
+    if (window) {
+        WSortArgs w = {};
+        w.coords = coords; w.N = H * W; w.nbx = pl.nbx; w.nby = pl.nby; w.nb = pl.nb; w.nch = pl.nch; w.gmax = pl.qtiles;
+        w.cnt = (int*)((char*)workspace + pl.off_cnt); w.toff = (int*)((char*)workspace + pl.off_toff);
+        w.ngr = (int*)((char*)workspace + pl.off_ngr); w.qlist = (int*)((char*)workspace + pl.off_qlist);
+        hipLaunchKernelGGL(alt_wbucket_kernel<false>, dim3(pl.nb, pl.nch, B), dim3(64), 0, s, w);
+        if ((rc = check_launch("alt_wbucket_kernel<count>"))) return rc;
+        hipLaunchKernelGGL(alt_wscan_kernel, dim3(B), dim3(1024), 0, s, w);
+        if ((rc = check_launch("alt_wscan_kernel"))) return rc;
+        hipLaunchKernelGGL(alt_wbucket_kernel<true>, dim3(pl.nb, pl.nch, B), dim3(64), 0, s, w);
+        if ((rc = check_launch("alt_wbucket_kernel<fill>"))) return rc;
+        a.qlist = w.qlist; a.ngr = w.ngr;
+        a.dg = (float*)((char*)workspace + pl.off_dg);
+        uint4* f1g = (uint4*)((char*)workspace + pl.off_f1g);
+        a.f1t = f1g;
+        hipLaunchKernelGGL(alt_wgather_f1_kernel, dim3(pl.qtiles, pl.Cp / 32, B), dim3(256), 0, s, (const uint4*)f1p_window, f1g,
+                           a.qlist, a.ngr, pl.qtiles, pl.Cp, (size_t)H * W);
+        if ((rc = check_launch("alt_wgather_f1_kernel"))) return rc;
+    }
+    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3(B * L * pl.qtiles + DMAXP), dim3(window ? 256 : 64), 0, s, a, B * L * pl.qtiles,
                        (size_t)B * L * rd2 * H * W);
-    int rc = check_launch("alt_bwd_pre_kernel");
+    rc = check_launch("alt_bwd_pre_kernel");
     if (rc) return rc;
     const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * std::max(rd2, 96) * sizeof(float);
     static thread_local bool allowed[64] = {};               // > 64 KiB of dynamic LDS: opt in once per device

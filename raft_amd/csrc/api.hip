@@ -456,6 +456,33 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
                                    (hipStream_t)stream);
 }
 
+int64_t raftcorr_alt_lookup_bwd_sorted_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius)
+{
+    if (B < 1 || H < 1 || W < 1 || C < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || radius < 0) return 0;
+    return (int64_t)alt_lookup_bwd_workspace_bytes(B, H, W, C, num_levels, radius, true);
+}
+
+int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles2_levels, const float* scales,
+                                   int B, int H, int W, int C, int num_levels, int radius,
+                                   const float* coords, const float* dout, float* dfmap1, float* const* dfmap2_levels,
+                                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    int rc = check_dims("alt_lookup_bwd_sorted", B, H, W);
+    if (rc) return rc;
+    if (!packed1 || !tiles2_levels || !scales || !coords || !dout || !dfmap1 || !dfmap2_levels)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: null pointer");
+    if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: C=%d radius=%d", C, radius);
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: level %d of a %d x %d map is empty", l, H, W);
+        if (!tiles2_levels[l] || !dfmap2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: level %d pointer is null", l);
+    }
+    return launch_alt_lookup_bwd16(nullptr, tiles2_levels, scales, B, H, W, C, num_levels, radius, coords, dout, dfmap1,
+                                   dfmap2_levels, accumulate, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
+                                   (hipStream_t)stream, packed1);
+}
+
 int64_t raftcorr_alt_prepare_workspace_bytes(int B, int C, int H, int W, int num_levels)
 {
     if (B < 1 || C < 1 || H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS) return 0;

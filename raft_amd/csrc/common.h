@@ -60,7 +60,7 @@ size_t alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int L);
 int launch_maxabs1(const float* x, size_t n, float* out, hipStream_t s);
 size_t alt_tiles_bytes(int B, int C, int H, int W);
 int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
-size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r);
+size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window = false);
 size_t alt_prepare_workspace_bytes(int B, int C, int H, int W, int L);
 int launch_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int H, int W, int L, float* scales,
                        void* packed1, void* const* packed2, void* tiles1, void* const* tiles2,
@@ -69,7 +69,7 @@ int launch_alt_features_bwd(const float* d1, const float* const* d2, int B, int 
                             float* df1, float* df2, hipStream_t s);
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t s);
+                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window = nullptr);
 
 // floor + fraction of a sampling coordinate, memory-safe for NaN / huge values: anything
 // that is not a sane pixel coordinate is pushed far outside the map (all taps read as zero).

@@ -754,6 +754,30 @@ def test_on_the_fly_backward_is_bit_reproducible(dev):
     assert np.isfinite(grads[0][0]).all() and np.abs(grads[0][1]).max() > 0
 
 
+def test_on_the_fly_window_groups_backward_is_bit_reproducible(dev):
+    """tiles="window": raftcorr_alt_lookup_bwd_sorted forms its query groups without atomics (buckets in cell order,
+    members in query order), so two runs agree bit for bit -- rough flow, more than one group per bucket, empty
+    buckets, coordinates outside the map -- and agree with the pixel-tile backward to the order of the sums."""
+    from raft_amd import AlternateCorrBlock
+    rs = np.random.RandomState(9)
+    B, D, H, W, L, r = 2, 96, 47, 78, 4, 4
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    con = np.stack([xx, yy], 0)[None].astype(np.float32) + 6.0 * rs.randn(B, 2, H, W).astype(np.float32)
+    con[0, :, :6, :] = [[[30.0]], [[20.0]]]                        # hundreds of queries in one bucket
+    con[1, :, 3, 3] = [1e9, -4.0]
+    gn = rs.randn(B, L * 81, H, W).astype(np.float32)
+    grads = {}
+    for tiles in ("window", "window", "pixel"):
+        f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+        AlternateCorrBlock(f1, f2, num_levels=L, radius=r, tiles=tiles)(_t(con, dev)).backward(_t(gn, dev))
+        grads.setdefault(tiles, []).append((f1.grad.cpu().numpy(), f2.grad.cpu().numpy()))
+    (a1, a2), (b1, b2) = grads["window"]
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+    p1, p2 = grads["pixel"][0]
+    assert rel_err(a1, p1) <= 2e-6 and rel_err(a2, p2) <= 2e-6
+
+
 def test_on_the_fly_gradients_sum_in_place(dev):
     """The lookups of one AlternateCorrBlock add their feature gradients into shared sums inside the backward
     kernel (accumulate = 1) instead of handing autograd one dense gradient per lookup.  Same bits as the sum of the

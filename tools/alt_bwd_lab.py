@@ -27,8 +27,16 @@ with torch.no_grad():
     work = torch.empty(wb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     res = {}
-    for tag, c in (("identity", coords[0]), ("sigma3", coords[1]), ("sigma4.2", coords[2]), ("sigma6", coords[4])):
+    for tag, c in (() if os.environ.get("WINDOW_ONLY") else (("identity", coords[0]), ("sigma3", coords[1]), ("sigma4.2", coords[2]), ("sigma6", coords[4]))):
         res[tag] = round(bench.ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd(
             blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, D, L, R, c.data_ptr(), gout.data_ptr(),
             d1.data_ptr(), dlv, int(os.environ.get('ACC', '0')), work.data_ptr(), wb, st), reps=30, warm=5), 1)
+    swb = lib.raftcorr_alt_lookup_bwd_sorted_workspace_bytes(B, H, W, D, L, R)
+    swork = torch.empty(swb, dtype=torch.uint8, device=dev)
+    res_w = {}
+    for tag, c in (("identity", coords[0]), ("sigma3", coords[1]), ("sigma4.2", coords[2]), ("sigma6", coords[4])):
+        res_w[tag] = round(bench.ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd_sorted(
+            blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, D, L, R, c.data_ptr(), gout.data_ptr(),
+            d1.data_ptr(), dlv, int(os.environ.get('ACC', '0')), swork.data_ptr(), swb, st), reps=30, warm=5), 1)
 print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt bwd us:", res, flush=True)
+print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt bwd, window groups, us:", res_w, flush=True)

@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/rc_var_$name; mkdir -p $obj
-for f in api build_pyramid lookup build_bwd alt_tile alt_fwd16 alt_bwd; do
+for f in api build_pyramid lookup build_bwd bwd_deferred alt_tile alt_fwd16 alt_bwd alt_prep; do
   [ -f $root/raft_amd/csrc/$f.hip ] || continue
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DRC_LAB "$@" -c $root/raft_amd/csrc/$f.hip -o $obj/$f.o &
 done
