@@ -96,7 +96,7 @@ def work_of(cfg):
     N = H * W
     rd, T = 2 * RADIUS + 1, 2 * RADIUS + 2
     cells = sum((H >> l) * (W >> l) for l in range(LEVELS))
-    w = {"N": N, "build_flops": 2.0 * B * N * N * D,
+    w = {"N": N, "B": B, "build_flops": 2.0 * B * N * N * D,
          "build_bytes": 2.0 * B * N * D * 4 + 4.0 * B * N * cells,
          "build_bytes_16": 2.0 * B * N * D * 4 + 2.0 * B * N * cells,       # 16-bit volume
          "lookup_bytes": float(B * N * (LEVELS * T * T * 4 + LEVELS * rd * rd * 4 + 8)),
@@ -119,6 +119,34 @@ def frac_entry(kernel, us, bound, amount, peak, unit, **kw):
          "frac": rate / peak}
     e.update(kw)
     return e
+
+
+def mfma16_entry(kernel, us, algorithmic_flops, terms, **kw):
+    """A kernel whose contraction runs on the 16-bit matrix cores as `terms` products per algorithmic product (fp16x2: 3,
+    bf16x3: 6): `frac` is EXECUTED flops against the dense 16-bit MFMA peak (the unit the kernel runs on, never > 1);
+    the algorithmic rate is given beside it with its ratio to the fp32-matrix peak SURVEY 8(d) names (a ratio, not a
+    roofline fraction: it exceeds 1 when the split arithmetic beats the fp32 unit)."""
+    ex = terms * algorithmic_flops
+    e = frac_entry(kernel, us, "mfma", ex, MFMA_16_PEAK_TFLOPS, "TFLOP/s", executed_flops=ex, mfma_terms=terms,
+                   algorithmic_flops=algorithmic_flops, algorithmic_TFLOPs=algorithmic_flops / us / 1e6,
+                   algorithmic_vs_fp32_mfma_peak=algorithmic_flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS)
+    e.update(kw)
+    return e
+
+
+def lookup_cap(w, vol_bytes=4):
+    """Where the lookup's fraction ON ALGORITHMIC BYTES ends for this access pattern: a (2r+1)^2 window is
+    fetched as the even-aligned (2r+4)^2 tile of 2x2 blocks; in lines of 4x8 cells (levels 0/1; 2x16 at levels 2/3, fp32)
+    that tile spans 3.5 x 2.25 resp. 6 x 1.6 lines = 31.6 lines of 128 B per query over 4 levels, and a bare gather of
+    such lines runs at 5.7 TB/s at best on this part (tools/gather_bw.hip): cap = algorithmic bytes / (line bytes +
+    output bytes) x 5.7 / 8."""
+    n = w["N"] * w.get("B", 1)
+    lines = 31.6 * 128.0 * n * (vol_bytes / 4.0)
+    out = n * LEVELS * (2 * RADIUS + 1) ** 2 * 4.0
+    alg = w["lookup_bytes"] if vol_bytes == 4 else w["lookup_bytes_16"]
+    return {"cap": alg / (lines + out) * 5.7 / 8.0,
+            "cap_derivation": "algorithmic bytes / (31.6 lines x 128 B per query + output) x 5.7 TB/s line-gather rate / 8 TB/s peak; "
+                              "the north star's 0.70 is not reachable with per-query slabs at fp32 (DESIGN 4.2)"}
 
 
 def flow_coords(torch, B, H, W, iters, g, sigma=3.0):
@@ -205,14 +233,16 @@ class SintelFwd(Workload):
         w = work_of(self.cfg)
         iters = CONFIGS[self.cfg][4]
         build_us, lookup_us = phases_us[0], phases_us[1] / iters
-        traffic = load_profile_json("r02_pmc_traffic_sintel.json") or load_profile_json("pmc_traffic.json")
+        tsrc = "r03_pmc_traffic_sintel.json" if load_profile_json("r03_pmc_traffic_sintel.json") else "r02_pmc_traffic_sintel.json"
+        traffic = load_profile_json(tsrc)
         kb = frac_entry("corr_build_f32_kernel (+ corr_pack_kernel)", build_us, "mfma", w["build_flops"],
                         MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=w["build_flops"],
                         algorithmic_bytes=w["build_bytes"], hbm_GBs=w["build_bytes"] / build_us / 1e3,
-                        traffic=traffic.get("corr_build_f32_kernel"),
+                        traffic=traffic.get("corr_build_f32_kernel"), traffic_source="profiles/" + tsrc + " (PMC passes, not live)",
                         note="us_per_launch = HIP events around the constructor: pack + build kernels + host gap")
         kl = frac_entry("corr_lookup_fwd_kernel", lookup_us, "hbm", w["lookup_bytes"], HBM_PEAK_GBS, "GB/s",
-                        algorithmic_bytes=w["lookup_bytes"], traffic=traffic.get("corr_lookup_fwd_kernel"))
+                        algorithmic_bytes=w["lookup_bytes"], traffic=traffic.get("corr_lookup_fwd_kernel"),
+                        traffic_source="profiles/" + tsrc + " (PMC passes, not live)", **lookup_cap(w))
         return {"build": kb, "lookup": kl}, ("build" if build_us >= phases_us[1] else "lookup")
 
 
@@ -229,7 +259,7 @@ class Bf16AllPairs(SintelFwd):
                         mfma_TFLOPs=w["build_flops"] / build_us / 1e6, traffic=None,
                         note="bf16 operands, bf16 pyramid: bound by the pyramid's store traffic")
         kl = frac_entry("corr_lookup_fwd_kernel<4, bf16 volume>", lookup_us, "hbm", w["lookup_bytes_16"], HBM_PEAK_GBS, "GB/s",
-                        algorithmic_bytes=w["lookup_bytes_16"], traffic=None)
+                        algorithmic_bytes=w["lookup_bytes_16"], traffic=None, **lookup_cap(w, 2))
         return {"build": kb, "lookup": kl}, ("build" if build_us >= phases_us[1] else "lookup")
 
 
@@ -262,18 +292,18 @@ class KittiAlt(Workload):
         iters = CONFIGS[self.cfg][4]
         fwd_us, bwd_us = phases_us[0] / iters, phases_us[1] / iters
         note = ("phase time / lookups: includes the feature pyramid and packs (fwd) and autograd glue (bwd); the product runs "
-                "on the 16-bit matrix cores (3 fp16 terms), fractions are of the fp32-matrix and HBM peaks of SURVEY 8(d)")
-        tr = load_profile_json("r02_pmc_traffic_kitti.json")
-        k = {"alt_fwd": frac_entry("alt_fwd16_kernel", fwd_us, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
-                                   "TFLOP/s", algorithmic_flops=w["alt_flops"], compulsory_bytes=w["alt_bytes"],
-                                   hbm_GBs=w["alt_bytes"] / fwd_us / 1e3,
-                                   hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, traffic=tr.get("alt_fwd16_kernel"),
-                                   note=note),
-             "alt_bwd": frac_entry("alt_bwd_kernel (+ range pass, windows, reduce)", bwd_us, "mfma", w["alt_bwd_flops"],
-                                   MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=w["alt_bwd_flops"],
-                                   compulsory_bytes=w["alt_bwd_bytes"], hbm_GBs=w["alt_bwd_bytes"] / bwd_us / 1e3,
-                                   hbm_frac=w["alt_bwd_bytes"] / bwd_us / 1e3 / HBM_PEAK_GBS,
-                                   traffic=tr.get("alt_bwd_kernel"), note=note)}
+                "on the 16-bit matrix cores (3 fp16 terms per product): frac = executed flops (useful taps x 3) / 2.5 PF; the tile "
+                "products cover whole boxes, i.e. the matrix cores execute several times that")
+        tsrc = "r03_pmc_traffic_kitti.json" if load_profile_json("r03_pmc_traffic_kitti.json") else "r02_pmc_traffic_kitti.json"
+        tr = load_profile_json(tsrc)
+        k = {"alt_fwd": mfma16_entry("alt_bucket_kernel + alt_fwd16_kernel", fwd_us, w["alt_flops"], 3,
+                                     compulsory_bytes=w["alt_bytes"], hbm_GBs=w["alt_bytes"] / fwd_us / 1e3,
+                                     hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, traffic=tr.get("alt_fwd16_kernel"),
+                                     traffic_source="profiles/" + tsrc, note=note),
+             "alt_bwd": mfma16_entry("alt_bwd_kernel (+ window groups, gathers, range pass, reduce)", bwd_us, w["alt_bwd_flops"], 3,
+                                     compulsory_bytes=w["alt_bwd_bytes"], hbm_GBs=w["alt_bwd_bytes"] / bwd_us / 1e3,
+                                     hbm_frac=w["alt_bwd_bytes"] / bwd_us / 1e3 / HBM_PEAK_GBS,
+                                     traffic=tr.get("alt_bwd_kernel"), traffic_source="profiles/" + tsrc, note=note)}
         return k, ("alt_bwd" if bwd_us >= fwd_us else "alt_fwd")
 
 
@@ -308,11 +338,12 @@ class ThingsTrain(Workload):
     def kernels(self, phases_us):
         w = work_of(self.cfg)
         k = {"fwd": {"kernel": "corr_pack + corr_build_f32 + 12 x corr_lookup_fwd", "us": phases_us[0]},
-             "bwd": {"kernel": "12 x corr_lookup_bwd + fold + 2 GEMMs (+ all-reduce when N > 1)", "us": phases_us[1]}}
+             "bwd": {"kernel": "12 x corr_record + corr_splat_fold + 2 GEMMs (+ all-reduce when N > 1, overlapped)", "us": phases_us[1]}}
         k["fwd"].update(frac_entry(k["fwd"]["kernel"], phases_us[0], "mfma", w["build_flops"], MFMA_F32_PEAK_TFLOPS,
                                    "TFLOP/s"))
-        k["bwd"].update(frac_entry(k["bwd"]["kernel"], phases_us[1], "mfma", 2 * w["gemm_flops"],
-                                   MFMA_F32_PEAK_TFLOPS, "TFLOP/s"))
+        k["bwd"].update(mfma16_entry(k["bwd"]["kernel"], phases_us[1], 2 * w["gemm_flops"], 3,
+                                     note="the two feature-gradient GEMMs run as 3 fp16 products on the 16-bit matrix cores; the phase "
+                                          "also holds the records and the fold-in-LDS kernel (HBM / LDS bound)"))
         return k, "bwd"
 
 
@@ -366,7 +397,7 @@ def extras_sintel(torch, wl, dev):
                 "corr_build_bf16_kernel (+ pack" + (" + max|x| pass)" if terms == 3 else ")"), t, "hbm",
                 w["build_bytes"], HBM_PEAK_GBS, "GB/s", algorithmic_bytes=w["build_bytes"],
                 algorithmic_TFLOPs=w["build_flops"] / t / 1e6, executed_16bit_TFLOPs=terms * w["build_flops"] / t / 1e6,
-                note=note)
+                mfma16_frac=terms * w["build_flops"] / t / 1e6 / MFMA_16_PEAK_TFLOPS, note=note)
         for prec, vol in (("bf16", "bf16"), ("fp16x2", "fp16")):
             t = ev_time_us(torch, lambda: CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision=prec, volume_dtype=vol),
                            reps=100, warm=30)
@@ -385,10 +416,9 @@ def extras_sintel(torch, wl, dev):
         alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
         for tag, c in (("alt_fwd_iter0", coords[0]), ("alt_fwd_iter8", coords[8])):
             t = ev_time_us(torch, lambda: alt(c))
-            out[tag] = frac_entry("alt_fwd_kernel", t, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                                  algorithmic_flops=w["alt_flops"], compulsory_bytes=w["alt_bytes"],
-                                  hbm_GBs=w["alt_bytes"] / t / 1e3, hbm_frac=w["alt_bytes"] / t / 1e3 / HBM_PEAK_GBS,
-                                  note="identity flow" if tag.endswith("0") else "flow = 8 steps of N(0, 3^2) drift per pixel")
+            out[tag] = mfma16_entry("alt_fwd16_kernel", t, w["alt_flops"], 3, compulsory_bytes=w["alt_bytes"],
+                                    hbm_GBs=w["alt_bytes"] / t / 1e3, hbm_frac=w["alt_bytes"] / t / 1e3 / HBM_PEAK_GBS,
+                                    note="identity flow" if tag.endswith("0") else "flow = 8 steps of N(0, 3^2) drift per pixel")
 
         def split_pair():
             cb = CorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, precision="fp16x2")
@@ -431,7 +461,9 @@ def extras_kitti(torch, wl, dev):
         o = torch.empty(B, LEVELS * 81, H, W, device=dev)
         swb = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, LEVELS)
         swork = torch.empty(swb, dtype=torch.uint8, device=dev)
-        for tag, c in (("identity", wl.coords[0]), ("sigma3", wl.coords[1]), ("sigma6", wl.coords[4])):
+        wwb = lib.raftcorr_alt_lookup_bwd_sorted_workspace_bytes(B, H, W, D, LEVELS, RADIUS)
+        wwork = torch.empty(wwb, dtype=torch.uint8, device=dev)
+        for tag, c in (("identity", wl.coords[0]), ("sigma3", wl.coords[1]), ("sigma6", wl.coords[4]), ("sigma10", wl.coords[11])):
             tf = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(),
                                                                       B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
                                                                       stream))
@@ -441,16 +473,21 @@ def extras_kitti(torch, wl, dev):
             ts = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_fwd_sorted(
                 blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, LEVELS, RADIUS, c.data_ptr(), o.data_ptr(),
                 swork.data_ptr(), swb, stream))
-            out["alt_fwd_window_tiles_" + tag] = frac_entry("alt_bucket_kernel + alt_fwd16_kernel", ts, "mfma", w["alt_flops"],
-                                                            MFMA_F32_PEAK_TFLOPS, "TFLOP/s", compulsory_bytes=w["alt_bytes"])
-            out["alt_fwd_" + tag] = frac_entry("alt_fwd16_kernel", tf, "mfma", w["alt_flops"], MFMA_F32_PEAK_TFLOPS,
-                                               "TFLOP/s", hbm_GBs=w["alt_bytes"] / tf / 1e3,
-                                               hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS,
-                                               compulsory_bytes=w["alt_bytes"])
-            out["alt_bwd_" + tag] = frac_entry("alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels", tb, "mfma", w["alt_bwd_flops"],
-                                               MFMA_F32_PEAK_TFLOPS, "TFLOP/s", hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
-                                               hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS,
-                                               compulsory_bytes=w["alt_bwd_bytes"])
+            tw = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd_sorted(gblk._p1.data_ptr(), gblk._t2ptrs, gblk._scales.data_ptr(),
+                                                                             B, H, W, D, LEVELS, RADIUS, c.data_ptr(), gout.data_ptr(),
+                                                                             d1.data_ptr(), dlv, 0, wwork.data_ptr(), wwb, stream))
+            hb = dict(compulsory_bytes=w["alt_bytes"])
+            out["alt_fwd_window_tiles_" + tag] = mfma16_entry("alt_bucket_kernel + alt_fwd16_kernel", ts, w["alt_flops"], 3, **hb)
+            out["alt_fwd_" + tag] = mfma16_entry("alt_fwd16_kernel", tf, w["alt_flops"], 3, hbm_GBs=w["alt_bytes"] / tf / 1e3,
+                                                 hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS, **hb)
+            hb = dict(compulsory_bytes=w["alt_bwd_bytes"])
+            out["alt_bwd_" + tag] = mfma16_entry("alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels", tb, w["alt_bwd_flops"], 3,
+                                                 hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
+                                                 hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS, **hb)
+            out["alt_bwd_window_groups_" + tag] = mfma16_entry(
+                "alt_wbucket x2 + alt_wscan + alt_wgather_f1 + alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels", tw,
+                w["alt_bwd_flops"], 3, hbm_GBs=w["alt_bwd_bytes"] / tw / 1e3,
+                hbm_frac=w["alt_bwd_bytes"] / tw / 1e3 / HBM_PEAK_GBS, **hb)
     # the whole step with 8x8 pixel tiles in the forward pass (the default of AlternateCorrBlock: flow fields are smooth)
     wl.tiles = "pixel"
     try:
@@ -496,18 +533,43 @@ def extras_things(torch, wl, dev):
         t = ev_time_us(torch, lambda: lib.raftcorr_build_bwd(wl.f1.data_ptr(), wl.f2.data_ptr(), B, D, H, W, LEVELS,
                                                               pyr.dptrs, d1.data_ptr(), d2.data_ptr(), work.data_ptr(),
                                                               wb, stream), reps=10, warm=2)
-        out["build_bwd"] = frac_entry("corr_fold_levels + cols_gather + 2 x gemm + reduce + cols_scatter", t, "mfma",
-                                      2 * w["gemm_flops"], MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                                      algorithmic_flops=2 * w["gemm_flops"], fold_bytes=w["fold_bytes"],
-                                      note="per-kernel split: profiles/ (rocprofv3 kernel trace of this config)")
-    prof = load_profile_json("r02_things_kernels.json")          # per-kernel durations from the committed trace
-    for name, us in prof.items():
-        if "fold" in name:
-            out["profile:" + name] = frac_entry(name, us, "hbm", w["fold_bytes"], HBM_PEAK_GBS, "GB/s",
-                                                source="profiles/r02_things_kernels.json")
+        out["build_bwd"] = mfma16_entry("corr_fold_levels + cols_gather + 2 x gemm (fp16x2) + reduce + cols_scatter", t,
+                                        2 * w["gemm_flops"], 3, fold_bytes=w["fold_bytes"],
+                                        note="the accumulate route (raftcorr_lookup_bwd x K into a dense gradient pyramid, then this)")
+        del work
+        # the deferred route (what CorrBlock's backward runs at this shape): K records + one fold-in-LDS kernel + the GEMMs
+        iters = CONFIGS[wl.cfg][4]
+        C = LEVELS * (2 * RADIUS + 1) ** 2
+        recs = [torch.empty(B, H * W, C, device=dev) for _ in range(iters)]
+        t = ev_time_us(torch, lambda: lib.raftcorr_lookup_bwd_record(go.data_ptr(), B, H, W, C, recs[0].data_ptr(), stream),
+                       reps=50, warm=5)
+        out["lookup_bwd_record"] = frac_entry("corr_record_kernel", t, "hbm", 2.0 * go.numel() * 4, HBM_PEAK_GBS, "GB/s",
+                                              algorithmic_bytes=2.0 * go.numel() * 4,
+                                              note="d(out) (B, C, H, W) -> (B, N, C), once per lookup of the backward pass")
+        for k in range(iters):
+            _lib.check(lib.raftcorr_lookup_bwd_record(wl.gouts[k].data_ptr(), B, H, W, C, recs[k].data_ptr(), stream), "record")
+        dwb = lib.raftcorr_build_bwd_deferred_workspace_bytes(B, D, H, W)
+        dwork = torch.empty(dwb, dtype=torch.uint8, device=dev)
+        cp, rp = _lib.ptr_array(wl.coords), _lib.ptr_array(recs)
+        t = ev_time_us(torch, lambda: lib.raftcorr_build_bwd_deferred(wl.f1.data_ptr(), wl.f2.data_ptr(), B, D, H, W, LEVELS, RADIUS,
+                                                                       _lib.MODE_CANONICAL, iters, cp, rp, None, d1.data_ptr(),
+                                                                       d2.data_ptr(), dwork.data_ptr(), dwb, stream), reps=10, warm=2)
+        d0_bytes = 4.0 * B * H * W * pyr.layout[0][2]
+        out["build_bwd_deferred"] = mfma16_entry(
+            "corr_splat_fold (all %d lookups, all levels) + cols_gather + 2 x gemm (fp16x2) + reduce + cols_scatter" % iters, t,
+            2 * w["gemm_flops"], 3, splat_fold_bytes=iters * go.numel() * 4.0 + d0_bytes,
+            note="replaces K x raftcorr_lookup_bwd + zero fill + fold: the folded level-0 gradient is made in LDS and written once")
+    prof = load_profile_json("r03_things_kernels.json") or load_profile_json("r02_things_kernels.json")
+    psrc = "profiles/r03_things_kernels.json" if load_profile_json("r03_things_kernels.json") else "profiles/r02_things_kernels.json"
+    for name, us in prof.items():                                # per-kernel durations from the committed trace
+        if "splat_fold" in name:
+            out["profile:" + name] = frac_entry(name, us, "hbm", iters * 4.0 * B * H * W * C + d0_bytes,
+                                                HBM_PEAK_GBS, "GB/s", source=psrc,
+                                                note="LDS / issue bound, not HBM bound (DESIGN 4.3): bytes = records read + dC0 written")
+        elif "fold" in name:
+            out["profile:" + name] = frac_entry(name, us, "hbm", w["fold_bytes"], HBM_PEAK_GBS, "GB/s", source=psrc)
         elif "gemm" in name and "reduce" not in name:
-            out["profile:" + name] = frac_entry(name, us, "mfma", w["gemm_flops"], MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                                                source="profiles/r02_things_kernels.json")
+            out["profile:" + name] = mfma16_entry(name, us, w["gemm_flops"], 3, source=psrc)
     return out
 
 
@@ -528,23 +590,33 @@ def extras_1080p(torch, wl, dev):
                             reps=5, warm=1)
             lb = w["lookup_bytes"] if vol == "fp32" else w["lookup_bytes_16"]
             bb = w["build_bytes"] if vol == "fp32" else w["build_bytes_16"]
+            terms = {"fp32": 0, "fp16x2": 3, "bf16": 1}[prec]
             out[f"all_pairs_{prec}_{vol}vol"] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_pair": t / 1e3, "build_us": tb,
                                                  "build_TFLOPs": w["build_flops"] / tb / 1e6,
+                                                 "build_mfma_frac": (w["build_flops"] / tb / 1e6 / MFMA_F32_PEAK_TFLOPS if terms == 0 else
+                                                                     terms * w["build_flops"] / tb / 1e6 / MFMA_16_PEAK_TFLOPS),
+                                                 "build_mfma_unit": "fp32 matrix (157.3 TF)" if terms == 0 else f"16-bit matrix (2500 TF), {terms} term(s) executed",
                                                  "build_hbm_frac": bb / tb / 1e3 / HBM_PEAK_GBS,
                                                  "lookup_us": (t - tb) / iters,
                                                  "lookup_hbm_frac": lb / ((t - tb) / iters) / 1e3 / HBM_PEAK_GBS}
             torch.cuda.empty_cache()
-        alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS)
+        for tiles in ("pixel", "window"):
+            alt = AlternateCorrBlock(f1, f2, num_levels=LEVELS, radius=RADIUS, tiles=tiles)
 
-        def alt_pair():
-            for c in coords:
-                alt(c)
-        t = ev_time_us(torch, alt_pair, reps=3, warm=1)
-        out["on_the_fly"] = {"frame_pairs_per_sec": 1e6 / t, "ms_per_pair": t / 1e3, "alt_fwd_us": t / iters,
-                             "alt_TFLOPs": w["alt_flops"] / (t / iters) / 1e6,
-                             "mfma_frac": w["alt_flops"] / (t / iters) / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                             "hbm_frac": w["alt_bytes"] / (t / iters) / 1e3 / HBM_PEAK_GBS,
-                             "memory": "no volume (features only)"}
+            def alt_pair():
+                for c in coords:
+                    alt(c)
+            t = ev_time_us(torch, alt_pair, reps=3, warm=1)
+            out["on_the_fly" + ("" if tiles == "pixel" else "_window_tiles")] = {
+                "frame_pairs_per_sec": 1e6 / t, "ms_per_pair": t / 1e3, "alt_fwd_us": t / iters,
+                "alt_TFLOPs": w["alt_flops"] / (t / iters) / 1e6,
+                "mfma16_frac": 3 * w["alt_flops"] / (t / iters) / 1e6 / MFMA_16_PEAK_TFLOPS,
+                "algorithmic_vs_fp32_mfma_peak": w["alt_flops"] / (t / iters) / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                "hbm_frac": w["alt_bytes"] / (t / iters) / 1e3 / HBM_PEAK_GBS,
+                "tiles": tiles + (" (8x8 pixel tiles; the coordinates are per-pixel random walks, the worst case for them)"
+                                  if tiles == "pixel" else " (queries grouped by window position)"),
+                "memory": "no volume (features only)"}
+            del alt
     return out
 
 
@@ -770,9 +842,9 @@ def main():
     phases = [float(np.median([e[i].elapsed_time(e[i + 1]) for e in ev])) * 1e3 for i in range(wl.n_events - 1)]
     kernels, dom = wl.kernels(phases)
     what = {"sintel": f"fp32 all-pairs build + {LEVELS}-level pyramid + {iters}-iter canonical lookup fwd (r={RADIUS})",
-            "kitti_alt": f"AlternateCorrBlock (on-the-fly, forward query tiles by {KittiAlt.tiles}), {iters} lookups fwd + bwd "
+            "kitti_alt": f"AlternateCorrBlock (on-the-fly, query tiles by {KittiAlt.tiles} position in both passes), {iters} lookups fwd + bwd "
                          f"(r={RADIUS}, {LEVELS} levels)",
-            "things_train": f"fp32 all-pairs build + {iters} lookups, fwd + bwd"
+            "things_train": f"fp32 all-pairs build + {iters} lookups, fwd + bwd (deferred lookup backward)"
                             + (f" + all-reduce of {GRAD_BUCKET} fp32 (RCCL)" if world > 1 else ""),
             "1080p": f"bf16-operand MFMA all-pairs build (bf16 pyramid) + {iters}-iter lookup fwd"}[args.config]
     line["config"] = {"workload": f"{args.config}: {img_h}x{img_w} -> {H}x{W} (N={H * W}), batch {B}/GPU, D={D}, {what} "
@@ -785,7 +857,8 @@ def main():
     if args.config == "1080p":
         line["dtype"] = "bf16"
     d = kernels[dom]
-    line["roofline"] = {k: d.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}
+    line["roofline"] = {k: d.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                  "cap", "cap_derivation") if k in d or k in ("traffic",)}
     line["kernels"] = kernels
     if args.config in ("sintel", "1080p"):
         line["us_per_build"] = phases[0]

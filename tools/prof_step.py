@@ -37,13 +37,15 @@ with torch.no_grad():
         alt(coords[0]); alt(coords[2])
 if not big:
     g1, g2 = f1.detach().clone().requires_grad_(True), f2.detach().clone().requires_grad_(True)
-    gout = gouts[0] if gouts is not None else torch.randn(f1.shape[0], L * (2 * R + 1) ** 2, *f1.shape[-2:], device=dev)
-    for _ in range(steps):                                   # backward kernels (3 lookups per pair)
+    K = len(coords) if cfg in ("kitti_alt", "things_train") else 3      # those two: the bench step itself
+    gs = gouts[:K] if gouts is not None else [torch.randn(f1.shape[0], L * (2 * R + 1) ** 2, *f1.shape[-2:], device=dev)] * K
+    for _ in range(steps):                                   # backward kernels
         g1.grad = g2.grad = None
         cb = CorrBlock(g1, g2, num_levels=L, radius=R)
-        torch.autograd.backward([cb(c) for c in coords[:3]], [gout] * 3)
+        torch.autograd.backward([cb(c) for c in coords[:K]], gs)
         g1.grad = g2.grad = None
-        ab = AlternateCorrBlock(g1, g2, num_levels=L, radius=R)
-        torch.autograd.backward([ab(c) for c in (coords[0], coords[2])], [gout] * 2)
+        ab = AlternateCorrBlock(g1, g2, num_levels=L, radius=R, tiles="window" if cfg == "kitti_alt" else "pixel")
+        torch.autograd.backward([ab(c) for c in coords[:K]], gs)
+        del cb, ab
 torch.cuda.synchronize()
 print("done")
