@@ -1,4 +1,4 @@
-"""RAFT-basic inference/training model on stock PyTorch modules, with the correlation block injected.
+"""RAFT-basic and RAFT-small inference/training models on stock PyTorch modules, with the correlation block injected.
 
 Why it exists: the correlation path is only meaningful inside RAFT's
 recurrent loop -- every lookup's coordinates depend on the previous lookup's output -- so the
@@ -9,6 +9,9 @@ architecture and the parameter names follow the reference so that its checkpoint
   motion encoder + SepConvGRU + flow head + mask head  core/update.py:6-14,33-60,79-97,114-136
   loop, pixel-unit coords, convex upsampling  core/raft.py:65-85,87-145
   InputPadder  core/utils/utils.py:7-24
+  RAFT-small (RAFT(..., small=True)): core/raft.py:31-35,50-53 (hidden 96, context 64, radius 3, 128-channel features),
+  bottleneck encoder core/extractor_origin.py:58-113,192-263, motion encoder + ConvGRU core/update.py:16-31,62-77,99-112,
+  bilinear x8 upsampling instead of the convex mask (core/raft.py:135-136)
 The model never imports a correlation implementation: `corr_factory(fmap1, fmap2)` must return a
 callable `coords (B,2,H/8,W/8) -> (B, 4*81, H/8, W/8)` (raft_amd.CorrBlock, raft_amd.AlternateCorrBlock,
 or the oracle's restatement of the reference).
@@ -26,6 +29,8 @@ def _norm(kind, ch):
         return nn.InstanceNorm2d(ch)
     if kind == "batch":
         return nn.BatchNorm2d(ch)
+    if kind == "none":
+        return nn.Sequential()
     raise ValueError(kind)
 
 
@@ -72,6 +77,96 @@ class BasicEncoder(nn.Module):
         x = F.relu(self.norm1(self.conv1(x)))
         x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return torch.split(x, [n, n], 0) if pair else x
+
+
+class Bottleneck(nn.Module):
+    """1x1 (to a quarter of the width) -> 3x3 (carries the stride) -> 1x1, residual."""
+
+    def __init__(self, cin, cout, norm, stride):
+        super().__init__()
+        mid = cout // 4
+        self.conv1 = nn.Conv2d(cin, mid, 1)
+        self.conv2 = nn.Conv2d(mid, mid, 3, padding=1, stride=stride)
+        self.conv3 = nn.Conv2d(mid, cout, 1)
+        self.norm1, self.norm2, self.norm3 = _norm(norm, mid), _norm(norm, mid), _norm(norm, cout)
+        self.downsample = None
+        if stride != 1:
+            self.norm4 = _norm(norm, cout)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride), self.norm4)
+
+    def forward(self, x):
+        y = F.relu(self.norm1(self.conv1(x)))
+        y = F.relu(self.norm2(self.conv2(y)))
+        y = F.relu(self.norm3(self.conv3(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(x + y)
+
+
+class SmallEncoder(nn.Module):
+    """1/8-resolution encoder of RAFT-small: 7x7 s2 stem (32), three 2-bottleneck stages (32, 64 s2, 96 s2), 1x1 head."""
+
+    def __init__(self, output_dim, norm):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 32, 7, stride=2, padding=3)
+        self.norm1 = _norm(norm, 32)
+        cin = 32
+        for i, (w, s) in enumerate(zip((32, 64, 96), (1, 2, 2)), start=1):
+            setattr(self, f"layer{i}", nn.Sequential(Bottleneck(cin, w, norm, s), Bottleneck(w, w, norm, 1)))
+            cin = w
+        self.conv2 = nn.Conv2d(96, output_dim, 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        pair = isinstance(x, (tuple, list))
+        if pair:
+            n = x[0].shape[0]
+            x = torch.cat(x, 0)
+        x = F.relu(self.norm1(self.conv1(x)))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return torch.split(x, [n, n], 0) if pair else x
+
+
+class SmallMotionEncoder(nn.Module):
+    def __init__(self, radius):
+        super().__init__()
+        self.convc1 = nn.Conv2d(CORR_LEVELS * (2 * radius + 1) ** 2, 96, 1)
+        self.convf1 = nn.Conv2d(2, 64, 7, padding=3)
+        self.convf2 = nn.Conv2d(64, 32, 3, padding=1)
+        self.conv = nn.Conv2d(128, 80, 3, padding=1)
+
+    def forward(self, flow, corr):
+        # `corr`: the (B, 196, H, W) lookup result, or relu(convc1(lookup)) when the block fused it (96 channels)
+        c1 = corr if corr.shape[1] == self.convc1.out_channels else F.relu(self.convc1(corr))
+        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        return torch.cat([F.relu(self.conv(torch.cat([c1, flo], 1))), flow], 1)
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, hidden, inp):
+        super().__init__()
+        for gate in "zrq":
+            setattr(self, "conv" + gate, nn.Conv2d(hidden + inp, hidden, 3, padding=1))
+
+    def forward(self, h, x):
+        hx = torch.cat([h, x], 1)
+        z, r = torch.sigmoid(self.convz(hx)), torch.sigmoid(self.convr(hx))
+        q = torch.tanh(self.convq(torch.cat([r * h, x], 1)))
+        return (1 - z) * h + z * q
+
+
+class SmallUpdateBlock(nn.Module):
+    def __init__(self, radius, hidden=96):
+        super().__init__()
+        self.encoder = SmallMotionEncoder(radius)
+        self.gru = ConvGRU(hidden, 82 + 64)
+        self.flow_head = FlowHead(hidden, 128)
+
+    def forward(self, net, inp, corr, flow):
+        net = self.gru(net, torch.cat([inp, self.encoder(flow, corr)], 1))
+        return net, None, self.flow_head(net)
 
 
 class BasicMotionEncoder(nn.Module):
@@ -169,17 +264,31 @@ class InputPadder:
         return x[..., c[0]:c[1], c[2]:c[3]]
 
 
+def upflow8(flow):
+    """(B,2,H,W) -> (B,2,8H,8W), bilinear, align_corners=True, values x8 (core/utils/utils.py:80-82)."""
+    return 8 * F.interpolate(flow, size=(8 * flow.shape[2], 8 * flow.shape[3]), mode="bilinear", align_corners=True)
+
+
 class RAFT(nn.Module):
-    def __init__(self, corr_factory, fuse_convc1=False):
+    def __init__(self, corr_factory, fuse_convc1=False, small=False):
         """fuse_convc1: the correlation block must offer lookup_conv1x1 (differentiable)
         (raft_amd.CorrBlock does): the motion encoder's first 1x1 conv + ReLU then runs inside
-        the lookup kernel and the (B, 324, H, W) tensor is never materialised."""
+        the lookup kernel and the (B, 324, H, W) tensor is never materialised.
+        small: RAFT-small -- the factory must build a radius-3 block on 128-channel features."""
         super().__init__()
         self.corr_factory = corr_factory
         self.fuse_convc1 = fuse_convc1
-        self.fnet = BasicEncoder(256, "instance")
-        self.cnet = BasicEncoder(HIDDEN + CONTEXT, "batch")
-        self.update_block = BasicUpdateBlock()
+        self.small = small
+        if small:
+            self.hidden, self.context = 96, 64
+            self.fnet = SmallEncoder(128, "instance")
+            self.cnet = SmallEncoder(self.hidden + self.context, "none")
+            self.update_block = SmallUpdateBlock(radius=3, hidden=self.hidden)
+        else:
+            self.hidden, self.context = HIDDEN, CONTEXT
+            self.fnet = BasicEncoder(256, "instance")
+            self.cnet = BasicEncoder(HIDDEN + CONTEXT, "batch")
+            self.update_block = BasicUpdateBlock()
 
     def load_reference_checkpoint(self, state_dict):
         """Accepts the reference's DataParallel checkpoints (keys prefixed with `module.`)."""
@@ -191,7 +300,7 @@ class RAFT(nn.Module):
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         fmap1, fmap2 = self.fnet([image1, image2])
         corr_fn = self.corr_factory(fmap1.float(), fmap2.float())
-        net, inp = torch.split(self.cnet(image1), [HIDDEN, CONTEXT], 1)
+        net, inp = torch.split(self.cnet(image1), [self.hidden, self.context], 1)
         net, inp = torch.tanh(net), torch.relu(inp)
         B, _, H, W = image1.shape
         coords0 = coords_grid(B, H // 8, W // 8, image1.device)
@@ -206,7 +315,7 @@ class RAFT(nn.Module):
                 corr = corr_fn(coords1)
             net, mask, delta = self.update_block(net, inp, corr, coords1 - coords0)
             coords1 = coords1 + delta
-            preds.append(convex_upsample(coords1 - coords0, mask))
+            preds.append(upflow8(coords1 - coords0) if mask is None else convex_upsample(coords1 - coords0, mask))
         return (coords1 - coords0, preds[-1]) if test_mode else preds
 
 

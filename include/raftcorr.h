@@ -225,10 +225,12 @@ int raftcorr_alt_forward(const float* fmap1, const float* fmap2, const float* co
 /* Drop-in for alt_cuda_corr.backward (alt_cuda_corr/correlation.cpp:36-48 ->
  * correlation_kernel.cu:288-324).  fmap1_grad (B,H1,W1,C), fmap2_grad (B,H2,W2,C) and
  * coords_grad (B,N,H1,W1,2) are fully overwritten; coords_grad is all zeros, as in the
- * reference (allocated at :307 and never written). coords_grad may be NULL.  Like the reference kernel
- * (atomicAdd at :229-238) this one-level drop-in zero-fills both gradients and adds into them with float
- * atomics, so the summation order -- not the value beyond rounding -- varies from run to run; the
- * all-level call below (raftcorr_alt_lookup_bwd) is the atomic-free, reproducible path. */
+ * reference (allocated at :307 and never written). coords_grad may be NULL.  fmap1_grad is summed in LDS by the
+ * workgroup that owns the query tile (over the N coordinate sets and the window boxes, in program order) and
+ * written once: no zero fill, no atomics, the same bits on every run (C <= 512; beyond that it falls back to float
+ * atomics).  fmap2_grad is a scatter across query tiles: like the reference kernel (atomicAdd at :229-238) it is
+ * zero-filled and added into with float atomics, so its summation order -- not the value beyond rounding -- varies
+ * from run to run; the all-level call below (raftcorr_alt_lookup_bwd) is the atomic-free, reproducible path. */
 int raftcorr_alt_backward(const float* fmap1, const float* fmap2, const float* coords,
                           const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
                           float* coords_grad,

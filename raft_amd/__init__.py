@@ -1,5 +1,5 @@
 """raft_amd -- MI355X-native correlation hot path of RAFT (drop-in for core/corr.py)."""
-from .corr import CorrBlock, AlternateCorrBlock, bilinear_sampler   # noqa: F401
+from .corr import CorrBlock, AlternateCorrBlock   # noqa: F401
 from . import alt_cuda_corr                                          # noqa: F401
 
-__all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler", "alt_cuda_corr"]
+__all__ = ["CorrBlock", "AlternateCorrBlock", "alt_cuda_corr"]

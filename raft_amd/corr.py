@@ -6,7 +6,9 @@ Same names, arguments and defaults as the reference:
 * ``CorrBlock(fmap1, fmap2, num_levels=2, radius=4)(coords)``       core/corr.py:12-61
 * ``CorrBlock.corr(fmap1, fmap2)``                                   core/corr.py:53-61
 * ``AlternateCorrBlock(fmap1, fmap2, num_levels=4, radius=4)(coords)`` core/corr.py:64-92
-* ``bilinear_sampler(img, coords)``                                  core/utils/utils.py:57-71
+
+(``utils.bilinear_sampler`` has no counterpart here: the window lookup is fused into raftcorr_lookup_fwd, and general
+sampling grids are outside the hot path -- callers keep the reference's own helper.)
 
 ``CorrBlock.__call__`` is bimodal: 3-D ``(B, N, 2)`` coords select the
 fork's semantics exactly as shipped (no per-level scaling, ``(B, N, C)`` output); 4-D
@@ -15,8 +17,11 @@ core/update.py:82-91 consume (coords / 2**l per level, ``(B, C, H, W)`` output).
 
 Autograd: the reference differentiates through matmul / avg_pool2d / grid_sample and
 materialises a dense, zero-filled gradient of a whole pyramid level for EVERY lookup.  Here
-all lookups of one CorrBlock accumulate into ONE gradient pyramid that is folded into the
-feature gradients once, when autograd reaches the build node.
+a lookup's backward only records (coords, d(out)); when autograd reaches the build node one
+kernel makes every query's folded level-0 gradient row in LDS and two contractions turn it into
+the feature gradients (``backward="deferred"``, the default where the shape allows it).  The
+older route -- all lookups accumulate into ONE dense gradient pyramid that is folded once --
+remains as ``backward="accumulate"`` and for gradients that arrive on the pyramid itself.
 
 PyTorch is used for device memory, streams and autograd bookkeeping only; there is no
 fallback path: without the HIP extension every operator raises RuntimeError.
@@ -35,7 +40,7 @@ try:                                    # CPython glue for the per-iteration cal
 except ImportError:                     # not built: the ctypes handle below does the same call
     _pyfast = None
 
-__all__ = ["CorrBlock", "AlternateCorrBlock", "bilinear_sampler"]
+__all__ = ["CorrBlock", "AlternateCorrBlock"]
 
 _ALIGN = 64   # level offsets inside the packed pyramid buffer, in elements (256 B)
 
@@ -551,23 +556,6 @@ class CorrBlock:
         B, D, H, W = fmap1.shape
         blk = CorrBlock(fmap1, fmap2, num_levels=1, radius=0)
         return blk.corr_pyramid[0].view(B, H, W, 1, H, W)
-
-
-def bilinear_sampler(img, coords, mode='bilinear', mask=False):
-    """core/utils/utils.py:57-71, same signature and semantics (pixel coords -> grid_sample with
-    align_corners=True, zero padding).  Kept for callers that import it from the corr module's
-    neighbourhood; CorrBlock itself does NOT use it -- the window lookup is fused into
-    raftcorr_lookup_fwd.  General sampling grids are outside the hot path (stock torch op)."""
-    H, W = img.shape[-2:]
-    xgrid, ygrid = coords.split([1, 1], dim=-1)
-    xgrid = 2 * xgrid / (W - 1) - 1
-    ygrid = 2 * ygrid / (H - 1) - 1
-    grid = torch.cat([xgrid, ygrid], dim=-1)
-    img = F.grid_sample(img, grid, align_corners=True)
-    if mask:
-        m = (xgrid > -1) & (ygrid > -1) & (xgrid < 1) & (ygrid < 1)
-        return img, m.float()
-    return img
 
 
 def _pack_conv_weight(lib, weight, cout, cin):

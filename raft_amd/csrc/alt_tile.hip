@@ -25,7 +25,7 @@
 //   d(fmap1)[c][q] = sum_u fmap2[c][u] G[q][u]      d(fmap2)[c][u] = sum_q fmap1[c][q] G[q][u]
 // d(fmap2) of a tile is added to memory with one float atomic per (channel, box target) instead
 // of one per (channel, query, tap) as in the reference (:239-250), 128 contiguous bytes per
-// wave-instruction; d(fmap1) is reduced over the four waves in LDS first.
+// wave-instruction; d(fmap1) belongs to the workgroup that owns the query tile and is summed in LDS (no atomics).
 //
 // Workgroups are numbered so that each XCD (workgroup id mod 8) owns a band of tile rows: the
 // band's part of fmap2 stays in that XCD's L2 while neighbouring tiles re-read it.
@@ -75,7 +75,9 @@ struct TileShared {
 };
 
 // queries' window origins + the bounding box of their in-level parts
-__device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh)
+// nset >= 0: the grid has no coordinate-set factor and this call sets up set `nset` (backward: one workgroup walks
+// the sets of its query tile in order)
+__device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh, int nset = -1)
 {
     Tile t;
     const int tiles_x = (p.W + TQW - 1) / TQW, tiles = tiles_x * ((p.H + TQH - 1) / TQH);
@@ -84,7 +86,8 @@ __device__ __forceinline__ Tile tile_setup(const AltTileArgs& p, TileShared& sh)
     const int tile = xcd * p.band + j;
     t.l = bl % p.L;
     const int bn = bl / p.L;
-    t.b = bn / p.Nc; t.n = bn - t.b * p.Nc;
+    if (nset >= 0) { t.b = bn; t.n = nset; }
+    else { t.b = bn / p.Nc; t.n = bn - t.b * p.Nc; }
     t.live = tile < tiles;
     if (!t.live) return t;                                       // whole workgroup
     t.ty0 = (tile / tiles_x) * TQH;
@@ -301,109 +304,133 @@ void alt_tile_fwd_kernel(AltTileArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward.  Same grid.
-template <bool VEC>
+// backward.  Grid: 8 XCD bands x (tiles per band x L x B) -- no coordinate-set factor: a workgroup owns its 32 queries'
+// d(fmap1) rows outright.  They are summed in LDS (acc1, dynamic: [TQ][C]) over the coordinate sets and the box chunks
+// in program order, the four waves' partial products through one LDS plane each added in wave order, and written
+// once with plain stores: d(fmap1) needs no zero fill, no atomics, and has the same bits on every run
+// (ACC1 = false, C too large for the LDS accumulator: float atomics into zero-filled memory, as round 1-2 did).
+// d(fmap2) is a scatter across tiles and keeps its float atomics (the all-level path alt_bwd.hip is the
+// reproducible one).
+template <bool VEC, bool ACC1>
 __global__ __launch_bounds__(256)
 void alt_tile_bwd_kernel(AltTileArgs p)
 {
+    extern __shared__ __attribute__((aligned(16))) float acc1[];    // ACC1: [TQ][C]
     __shared__ float F2s[KC * LDU];          // staged fmap2 chunk [c][u]; before the chunk loop: d(out) tile [ch][q]
     __shared__ float F1s[KC * LDQ];          // staged fmap1 chunk [c][q]
     __shared__ float G[TQ * LDU];            // tap gradients [q][u]
-    __shared__ float red[TQ * LDQ];          // d(fmap1) chunk [q][c], reduced over the waves
+    __shared__ float red[4][TQ * LDQ];       // d(fmap1) chunk [wave][q][c]
     __shared__ TileShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     const int r = p.r, T = 2 * r + 2, TT = T * T, rd = 2 * r + 1, rd2 = rd * rd;
-    const Tile t = tile_setup(p, sh);
-    if (!t.live) return;
-    const int bh = t.U / t.bw;
     const size_t P = (size_t)p.H * p.W;
-    const __amdgpu_buffer_rsrc_t f1b = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.f1) + (size_t)t.b * P * p.C, 0, (int)(P * p.C * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t f2b = __builtin_amdgcn_make_buffer_rsrc(
-        p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C, 0, t.HWl * p.C * 4, 0x00020000);
-    float* __restrict__ df1b = p.df1 + (size_t)t.b * P * p.C;
-    float* __restrict__ df2b = p.df2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
-    const int q_off = query_offset(p, t, tid & 31);
-    const int q_stage = query_offset(p, t, tid >> 3);
-    const float* __restrict__ dout = p.dout + (((size_t)t.b * p.Nc + t.n) * p.L + t.l) * rd2 * P;
     const float inv_div = 1.0f / p.out_div;
     const int nk = (p.C + KC - 1) / KC;
+    if (ACC1)
+        for (int e = tid; e < TQ * p.C; e += 256) acc1[e] = 0.f;
+    int q_stage = -1;
+    float* __restrict__ df1b = nullptr;
 
-    for (int ubase = 0; ubase < t.U; ubase += UC) {
-        __syncthreads();
-        float* Ds = F2s;                                            // [ch][q], stride 32
-        for (int e = tid; e < rd2 * TQ; e += 256)
-            Ds[e] = q_off >= 0 ? dout[(size_t)(e >> 5) * P + q_off] : 0.f;   // (e & 31) == (tid & 31)
-        for (int e = tid; e < TQ * LDU; e += 256) G[e] = 0.f;
-        sh.toff[tid] = box_offset(t, ubase + tid);
-        __syncthreads();
-        for (int e = tid; e < TT * TQ; e += 256) {
-            const int qi = e & 31, tp = e >> 5;
-            const int ty = tp / T, tx = tp - ty * T;
-            const int u = box_index(t, bh, sh.wy0[qi] + ty, sh.wx0[qi] + tx, ubase);
-            if (u >= 0) {
-                const float fx = sh.fx[qi], fy = sh.fy[qi];
-                float g = 0.f;
-                if (tx < rd && ty < rd) g += Ds[(tx * rd + ty) * TQ + qi] * ((1.f - fx) * (1.f - fy));
-                if (tx > 0 && ty < rd)  g += Ds[((tx - 1) * rd + ty) * TQ + qi] * (fx * (1.f - fy));
-                if (tx < rd && ty > 0)  g += Ds[(tx * rd + ty - 1) * TQ + qi] * ((1.f - fx) * fy);
-                if (tx > 0 && ty > 0)   g += Ds[((tx - 1) * rd + ty - 1) * TQ + qi] * (fx * fy);
-                G[qi * LDU + u] = g * inv_div;
+    for (int nset = 0; nset < p.Nc; ++nset) {
+        __syncthreads();                                            // the previous set's windows are no longer read
+        const Tile t = tile_setup(p, sh, nset);
+        if (!t.live) return;                                        // whole workgroup, every set alike
+        const int bh = t.U / t.bw;
+        const __amdgpu_buffer_rsrc_t f1b = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.f1) + (size_t)t.b * P * p.C, 0, (int)(P * p.C * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t f2b = __builtin_amdgcn_make_buffer_rsrc(
+            p.f2.ptr[t.l] + (size_t)t.b * t.HWl * p.C, 0, t.HWl * p.C * 4, 0x00020000);
+        df1b = p.df1 + (size_t)t.b * P * p.C;
+        float* __restrict__ df2b = p.df2.ptr[t.l] + (size_t)t.b * t.HWl * p.C;
+        const int q_off = query_offset(p, t, tid & 31);
+        q_stage = query_offset(p, t, tid >> 3);
+        const float* __restrict__ dout = p.dout + (((size_t)t.b * p.Nc + t.n) * p.L + t.l) * rd2 * P;
+
+        for (int ubase = 0; ubase < t.U; ubase += UC) {
+            __syncthreads();
+            float* Ds = F2s;                                            // [ch][q], stride 32
+            for (int e = tid; e < rd2 * TQ; e += 256)
+                Ds[e] = q_off >= 0 ? dout[(size_t)(e >> 5) * P + q_off] : 0.f;   // (e & 31) == (tid & 31)
+            for (int e = tid; e < TQ * LDU; e += 256) G[e] = 0.f;
+            sh.toff[tid] = box_offset(t, ubase + tid);
+            __syncthreads();
+            for (int e = tid; e < TT * TQ; e += 256) {
+                const int qi = e & 31, tp = e >> 5;
+                const int ty = tp / T, tx = tp - ty * T;
+                const int u = box_index(t, bh, sh.wy0[qi] + ty, sh.wx0[qi] + tx, ubase);
+                if (u >= 0) {
+                    const float fx = sh.fx[qi], fy = sh.fy[qi];
+                    float g = 0.f;
+                    if (tx < rd && ty < rd) g += Ds[(tx * rd + ty) * TQ + qi] * ((1.f - fx) * (1.f - fy));
+                    if (tx > 0 && ty < rd)  g += Ds[((tx - 1) * rd + ty) * TQ + qi] * (fx * (1.f - fy));
+                    if (tx < rd && ty > 0)  g += Ds[(tx * rd + ty - 1) * TQ + qi] * ((1.f - fx) * fy);
+                    if (tx > 0 && ty > 0)   g += Ds[((tx - 1) * rd + ty - 1) * TQ + qi] * (fx * fy);
+                    G[qi * LDU + u] = g * inv_div;
+                }
             }
-        }
-        const int ulive = min(t.U - ubase - wave * 64, 64);        // box targets of this wave, wave-uniform
-        Stage st;
-        stage_load<VEC>(st, f1b, f2b, 0, p.C, sh.toff, q_stage);
-        for (int kc = 0; kc < nk; ++kc) {
-            const int c0 = kc * KC;
-            __syncthreads();
-            stage_store(st, F2s, F1s);
-#pragma unroll
-            for (int i = 0; i < TQ * KC / 256; ++i) red[((tid >> 5) + 8 * i) * LDQ + (tid & 31)] = 0.f;
-            __syncthreads();
-            if (kc + 1 < nk) stage_load<VEC>(st, f1b, f2b, c0 + KC, p.C, sh.toff, q_stage);
-            if (ulive > 0) {
-                // d(fmap1)[q][c] += sum over this wave's box targets   (rows q, lanes c)
+            const int ulive = min(t.U - ubase - wave * 64, 64);        // box targets of this wave, wave-uniform
+            Stage st;
+            stage_load<VEC>(st, f1b, f2b, 0, p.C, sh.toff, q_stage);
+            for (int kc = 0; kc < nk; ++kc) {
+                const int c0 = kc * KC;
+                __syncthreads();
+                stage_store(st, F2s, F1s);
+                __syncthreads();
+                if (kc + 1 < nk) stage_load<VEC>(st, f1b, f2b, c0 + KC, p.C, sh.toff, q_stage);
                 v16f acc = {0};
-                const int ns = min((ulive + 1) >> 1, 32);
-                for (int s = 0; s < ns; ++s) {
-                    const int u = wave * 64 + 2 * s + kh;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(G[l31 * LDU + u], F2s[l31 * LDU + u], acc, 0, 0, 0);
+                if (ulive > 0) {
+                    // d(fmap1)[q][c] += sum over this wave's box targets   (rows q, lanes c)
+                    const int ns = min((ulive + 1) >> 1, 32);
+                    for (int s = 0; s < ns; ++s) {
+                        const int u = wave * 64 + 2 * s + kh;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(G[l31 * LDU + u], F2s[l31 * LDU + u], acc, 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    atomicAdd(&red[row * LDQ + l31], acc[i]);
-                }
-                // d(fmap2)[u][c] for this wave's box targets, all 32 queries   (rows u, lanes c)
-                v16f acc0 = {0}, acc1 = {0};
+                for (int i = 0; i < 16; ++i)                          // (zeros from a wave without box targets)
+                    red[wave][((i & 3) + 8 * (i >> 2) + 4 * kh) * LDQ + l31] = acc[i];
+                if (ulive > 0) {
+                    // d(fmap2)[u][c] for this wave's box targets, all 32 queries   (rows u, lanes c)
+                    v16f acc0 = {0}, acc1v = {0};
 #pragma unroll
-                for (int s = 0; s < TQ / 2; ++s) {
-                    const float b = F1s[l31 * LDQ + 2 * s + kh];
-                    const float a0 = G[(2 * s + kh) * LDU + wave * 64 + l31];
-                    const float a1 = G[(2 * s + kh) * LDU + wave * 64 + 32 + l31];
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
-                }
-                if (c0 + l31 < p.C) {
+                    for (int s = 0; s < TQ / 2; ++s) {
+                        const float b = F1s[l31 * LDQ + 2 * s + kh];
+                        const float a0 = G[(2 * s + kh) * LDU + wave * 64 + l31];
+                        const float a1 = G[(2 * s + kh) * LDU + wave * 64 + 32 + l31];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+                        acc1v = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1v, 0, 0, 0);
+                    }
+                    if (c0 + l31 < p.C) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                        const int o0 = sh.toff[wave * 64 + row], o1 = sh.toff[wave * 64 + 32 + row];
-                        if (o0 >= 0) atomicAdd(df2b + (size_t)o0 * p.C + c0 + l31, acc0[i]);
-                        if (o1 >= 0) atomicAdd(df2b + (size_t)o1 * p.C + c0 + l31, acc1[i]);
+                        for (int i = 0; i < 16; ++i) {
+                            const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                            const int o0 = sh.toff[wave * 64 + row], o1 = sh.toff[wave * 64 + 32 + row];
+                            if (o0 >= 0) atomicAdd(df2b + (size_t)o0 * p.C + c0 + l31, acc0[i]);
+                            if (o1 >= 0) atomicAdd(df2b + (size_t)o1 * p.C + c0 + l31, acc1v[i]);
+                        }
+                    }
+                }
+                __syncthreads();
+                {                                                     // thread (query tid >> 3, channel quad tid & 7)
+                    const int q = tid >> 3;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 4 * (tid & 7) + j;
+                        const float v = ((red[0][q * LDQ + c] + red[1][q * LDQ + c]) + red[2][q * LDQ + c]) + red[3][q * LDQ + c];
+                        if (c0 + c < p.C) {
+                            if (ACC1) acc1[q * p.C + c0 + c] += v;
+                            else if (q_stage >= 0) atomicAdd(df1b + (size_t)q_stage * p.C + c0 + c, v);
+                        }
                     }
                 }
             }
-            __syncthreads();
-            if (q_stage >= 0) {                                   // thread (query tid >> 3, channel quad tid & 7)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = 4 * (tid & 7) + j;
-                    if (c0 + c < p.C) atomicAdd(df1b + (size_t)q_stage * p.C + c0 + c, red[(tid >> 3) * LDQ + c]);
-                }
-            }
         }
+    }
+    if (ACC1) {
+        __syncthreads();
+        // (query offsets do not depend on the coordinate set: q_stage of the last set serves)
+        if (q_stage >= 0)
+            for (int c = tid & 7; c < p.C; c += 8) df1b[(size_t)q_stage * p.C + c] = acc1[(tid >> 3) * p.C + c];
     }
 }
 
@@ -438,17 +465,28 @@ int run_fwd(AltTileArgs& a, const char* who, hipStream_t s)
     return check_launch("alt_tile_fwd_kernel");
 }
 
-// zeroes d(fmap1) (and d(fmap2) of every level when zero_df2) and accumulates into them
+// d(fmap1) is overwritten (LDS accumulator; zero fill + atomics only when C is too large for it); d(fmap2) of every
+// level is zeroed when zero_df2 and accumulated with atomics
 int run_bwd(AltTileArgs& a, bool zero_df2, const char* who, hipStream_t s)
 {
     int rc = tile_prepare(a, who);
     if (rc) return rc;
-    hipError_t e = hipMemsetAsync(a.df1, 0, sizeof(float) * (size_t)a.B * a.C * a.H * a.W, s);
+    const size_t acc_bytes = sizeof(float) * (size_t)TQ * a.C;
+    const bool acc1 = acc_bytes <= 64 * 1024;
+    hipError_t e = hipSuccess;
+    if (!acc1) e = hipMemsetAsync(a.df1, 0, sizeof(float) * (size_t)a.B * a.C * a.H * a.W, s);
     for (int l = 0; zero_df2 && l < a.L && e == hipSuccess; ++l)
         e = hipMemsetAsync(a.df2.ptr[l], 0, sizeof(float) * (size_t)a.B * a.C * a.df2.g[l].h * a.df2.g[l].w, s);
     if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
-    if (a.vec) hipLaunchKernelGGL(alt_tile_bwd_kernel<true>, tile_grid(a), dim3(256), 0, s, a);
-    else       hipLaunchKernelGGL(alt_tile_bwd_kernel<false>, tile_grid(a), dim3(256), 0, s, a);
+    const dim3 grid(8u * a.band * a.L * a.B);                // one workgroup per query tile: it walks the Nc sets
+    typedef void (*Kern)(AltTileArgs);
+    const Kern kern = acc1 ? (a.vec ? alt_tile_bwd_kernel<true, true> : alt_tile_bwd_kernel<false, true>)
+                           : (a.vec ? alt_tile_bwd_kernel<true, false> : alt_tile_bwd_kernel<false, false>);
+    if (acc1) {                                              // static + dynamic LDS beyond 64 KiB: opt in
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "%s: %s", who, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), acc1 ? acc_bytes : 0, s, a);
     return check_launch("alt_tile_bwd_kernel");
 }
 

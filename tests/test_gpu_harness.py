@@ -13,9 +13,9 @@ from harness.raft_model import RAFT, InputPadder, sequence_loss, synthetic_pair
 pytestmark = pytest.mark.gpu
 
 
-def _flows(dev, factory, iters, size=(200, 320), seed=0, fuse=False):
+def _flows(dev, factory, iters, size=(200, 320), seed=0, fuse=False, small=False):
     torch.manual_seed(0)
-    model = RAFT(factory, fuse_convc1=fuse).to(dev).eval()
+    model = RAFT(factory, fuse_convc1=fuse, small=small).to(dev).eval()
     i1, i2, _ = synthetic_pair(1, *size, seed=seed, device=dev)
     pad = InputPadder(i1.shape)
     a, b = pad.pad(i1, i2)
@@ -45,6 +45,22 @@ def test_flow_matches_reference_corr_over_32_iterations(which, dev, reference_fl
     assert np.isfinite(ours[-1]).all() and np.abs(reference_flows[-1]).max() > 1.0    # the loop moved
     for it in (11, 31):
         assert _epe(ours[it], reference_flows[it]) <= 0.01, f"iteration {it + 1}"
+
+
+@pytest.mark.parametrize("which", ["all_pairs", "all_pairs_fused_convc1", "on_the_fly"])
+def test_raft_small_flow_matches_reference_corr(which, dev):
+    """RAFT-small (core/raft.py:31-35: radius 3, 128-channel features, 96-channel convc1, ConvGRU, bilinear upsampling)
+    around the same correlation blocks: EPE vs the run with the reference's CorrBlock <= 0.01 px after 12 and 32
+    iterations.  Exercises the radius-3 instantiations of the lookup kernels and the 196 -> 96 fused convolution."""
+    from oracle import corr_oracle as O
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    ref = _flows(dev, lambda a, b: O.CorrBlockOracle(a, b, 4, 3), 32, small=True)
+    fac = (lambda a, b: AlternateCorrBlock(a, b, num_levels=4, radius=3)) if which == "on_the_fly" else \
+          (lambda a, b: CorrBlock(a, b, num_levels=4, radius=3))
+    ours = _flows(dev, fac, 32, small=True, fuse=which.endswith("convc1"))
+    assert ours[-1].shape == ref[-1].shape and np.isfinite(ours[-1]).all() and np.abs(ref[-1]).max() > 1.0
+    for it in (11, 31):
+        assert _epe(ours[it], ref[it]) <= 0.01, f"iteration {it + 1}"
 
 
 def test_flow_with_fused_convc1_and_split_precision_build(dev, reference_flows):

@@ -328,6 +328,51 @@ def test_lookup_backward_accumulates_across_iterations(dev):
     assert rel_err(g1, o1) <= GTOL and rel_err(g2, o2) <= GTOL
 
 
+@pytest.mark.parametrize("block", ["all_pairs", "all_pairs_accumulate", "on_the_fly", "on_the_fly_window"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_16bit_feature_maps_with_requires_grad(block, dtype, dev):
+    """Mixed-precision callers (core/raft.py:99-103 runs the encoder under autocast and casts to float) may hand the
+    blocks 16-bit LEAF feature maps: the values are taken as they are (exact in fp32), outputs are float32, and the
+    gradients come back in the maps' dtype = the oracle's float32 gradients (same rounded inputs) rounded once."""
+    from raft_amd import AlternateCorrBlock, CorrBlock
+    from oracle import corr_oracle as O
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    rs = np.random.RandomState(77)
+    B, D, H, W, L, r, iters = 2, 24, 16, 24, 3, 4, 3
+    f1h = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32)).to(td)
+    f2h = torch.from_numpy(rs.randn(B, D, H, W).astype(np.float32)).to(td)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].repeat(B, 0).astype(np.float32)
+    coords = [base + (k + 1) * 0.8 * rs.randn(B, 2, H, W).astype(np.float32) for k in range(iters)]
+    gouts = [rs.randn(B, L * 81, H, W).astype(np.float32) for _ in range(iters)]
+
+    def run(make, device, leaf_dtype):
+        f1 = f1h.to(device=device, dtype=leaf_dtype).requires_grad_(True)
+        f2 = f2h.to(device=device, dtype=leaf_dtype).requires_grad_(True)
+        cb = make(f1, f2)
+        outs = [cb(torch.from_numpy(c).to(device)) for c in coords]
+        torch.autograd.backward(outs, [torch.from_numpy(g).to(device) for g in gouts])
+        return outs, f1.grad, f2.grad
+
+    make = {"all_pairs": lambda a, b: CorrBlock(a, b, num_levels=L, radius=r),
+            "all_pairs_accumulate": lambda a, b: CorrBlock(a, b, num_levels=L, radius=r, backward="accumulate"),
+            "on_the_fly": lambda a, b: AlternateCorrBlock(a, b, num_levels=L, radius=r),
+            "on_the_fly_window": lambda a, b: AlternateCorrBlock(a, b, num_levels=L, radius=r, tiles="window")}[block]
+    outs, g1, g2 = run(make, dev, td)
+    oo, o1, o2 = run(lambda a, b: O.CorrBlockOracle(a, b, L, r), "cpu", torch.float32)
+    assert all(o.dtype is torch.float32 for o in outs) and g1.dtype is td and g2.dtype is td
+    for o, ref in zip(outs, oo):
+        assert rel_err(o.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    # one rounding of the gradient to the leaf's dtype: half an ulp of 8 (bf16) / 11 (fp16) significand bits
+    bar = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[dtype]
+    errs = {"dfmap1": rel_err(g1.float().cpu().numpy(), o1.numpy()), "dfmap2": rel_err(g2.float().cpu().numpy(), o2.numpy())}
+    log_errors(f"16bit_leaf[{block},{dtype}]", **errs)
+    assert max(errs.values()) <= bar, errs
+    # and they are exactly the float32 gradients rounded: compare with our own float32-leaf run
+    _, h1, h2 = run(make, dev, torch.float32)
+    assert torch.equal(h1.to(td), g1) and torch.equal(h2.to(td), g2)
+
+
 def test_pyramid_tensors_are_differentiable(dev):
     """corr_pyramid entries carry autograd like the reference's (core/corr.py:24-27)."""
     from raft_amd import CorrBlock
@@ -464,7 +509,9 @@ def test_lookup_fused_with_convc1_backward(dev):
 # ---------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("case", [(2, 1, 11, 16, 11, 16, 64, 4), (1, 2, 9, 13, 5, 7, 32, 3),
-                                  (1, 1, 6, 7, 6, 7, 30, 2), (1, 1, 8, 8, 4, 4, 256, 4)])
+                                  (1, 1, 6, 7, 6, 7, 30, 2), (1, 1, 8, 8, 4, 4, 256, 4),
+                                  (1, 3, 10, 9, 20, 23, 48, 4),      # three coordinate sets, boxes walked in chunks
+                                  (1, 1, 5, 6, 5, 6, 520, 1)])       # C beyond the LDS accumulator: the atomic fallback
 def test_alt_cuda_corr_dropin_matches_c_oracle(case, dev):
     """raft_amd.alt_cuda_corr.forward/backward (the pybind surface of correlation.cpp:51-54)
     against the C restatement of the CUDA kernels."""
@@ -487,6 +534,21 @@ def test_alt_cuda_corr_dropin_matches_c_oracle(case, dev):
     assert rel_err(g1.cpu().numpy(), r1) <= GTOL
     assert rel_err(g2.cpu().numpy(), r2) <= GTOL
     assert gc.shape == tco.shape and not gc.any().item()
+    if C <= 512:
+        # fmap1_grad is owned by the query tile's workgroup (no atomics): the same bits on every run, and every element
+        # is written whatever the output buffer held before (C ABI, NaN-filled buffers)
+        from raft_amd import _lib
+        lib = _lib.load()
+        runs = []
+        for _ in range(3):
+            d1 = torch.full((B, H1, W1, C), float("nan"), device=dev)
+            d2 = torch.full((B, H2, W2, C), float("nan"), device=dev)
+            _lib.check(lib.raftcorr_alt_backward(tf1.data_ptr(), tf2.data_ptr(), tco.data_ptr(), tcg.data_ptr(),
+                                                 d1.data_ptr(), d2.data_ptr(), None, B, N, H1, W1, H2, W2, C, r,
+                                                 torch.cuda.current_stream().cuda_stream), "alt_backward")
+            runs.append(d1)
+            assert rel_err(d2.cpu().numpy(), r2) <= GTOL
+        assert torch.equal(runs[0], g1) and torch.equal(runs[1], g1) and torch.equal(runs[2], g1)
 
 
 def test_alt_cuda_corr_error_behaviour(dev):
