@@ -190,16 +190,22 @@ __device__ __forceinline__ void block_to_tile(const BuildArgs& p, int& b, int& t
 #define RC_EPI_AUX 0        // cache-policy bits of the epilogue's buffer stores (lab knob)
 #endif
 
-// 16-bit volume element (RAFTCORR_VOL_*): fp16 = RNE, beyond +-65504 -> inf; bf16 = RNE
+// 16-bit volume elements (RAFTCORR_VOL_*): fp16 = RNE, beyond +-65504 -> inf; bf16 = RNE, NaN stays NaN.  Two values
+// per hardware pack conversion (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32): a software RNE (and / compare / add / shift per
+// value) made the 16-bit-volume epilogue twice as long as the float32 one -- 480 of its ~800 vector instructions per
+// wave, on kernels whose matrix work is 64 MFMAs per wave.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <int VOL>
-__device__ __forceinline__ unsigned vol16(float x)
+__device__ __forceinline__ unsigned vol16_pair(float lo, float hi)        // lo -> bits 0..15, hi -> bits 16..31
 {
-    if (VOL == 1) return __builtin_bit_cast(unsigned short, (_Float16)x);
-    unsigned u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    const f32x2v v = {lo, hi};
+    if (VOL == 1) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
 }
+template <int VOL>
+__device__ __forceinline__ unsigned vol16(float x) { return vol16_pair<VOL>(x, 0.f) & 0xffffu; }
 
 typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
 
@@ -277,7 +283,7 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
             __builtin_amdgcn_raw_buffer_store_b128(w, r0, row * s0b + c0, 0, RC_EPI_AUX);    // 32 lanes = 512 contiguous bytes
         } else {
             u32x2s w;
-            w.x = vol16<VOL>(v[0]) | (vol16<VOL>(v[1]) << 16); w.y = vol16<VOL>(v[2]) | (vol16<VOL>(v[3]) << 16);
+            w.x = vol16_pair<VOL>(v[0], v[1]); w.y = vol16_pair<VOL>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b64(w, r0, row * s0b + c0, 0, RC_EPI_AUX);     // 32 lanes = 256 contiguous bytes
         }
         if (L > 1) {

@@ -77,6 +77,7 @@ int main(int argc, char** argv)
         pk.f2p = ws + (size_t)B * a.tilesM * D * 64; a.f1p = pk.f1p; a.f2p = pk.f2p;
         hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, block, 0, 0, pk);
         RUN("bf16 (1 piece)", corr_build_bf16_kernel<true, 1, false>);
+        RUN("bf16 (1 piece) -> bf16 volume", corr_build_bf16_kernel<true, 1, false, 2>);
         printf("pack bf16: %.1f us\n", timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, block, 0, 0, pk); }));
     }
     {   // 3 x bf16 operands
@@ -92,6 +93,7 @@ int main(int argc, char** argv)
         pk.maxpart = mp; a.maxpart = mp;
         hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk);
         RUN("fp16x2 (2 pieces, 3 products)", corr_build_bf16_kernel<true, 2, true>);
+        RUN("fp16x2 -> fp16 volume", corr_build_bf16_kernel<true, 2, true, 1>);
         printf("pack fp16x2: %.1f us, max|x| pass: %.1f us\n",
                timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk); }),
                timeit([&]() { hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp); }));
