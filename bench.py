@@ -559,6 +559,24 @@ def extras_things(torch, wl, dev):
             "corr_splat_fold (all %d lookups, all levels) + cols_gather + 2 x gemm (fp16x2) + reduce + cols_scatter" % iters, t,
             2 * w["gemm_flops"], 3, splat_fold_bytes=iters * go.numel() * 4.0 + d0_bytes,
             note="replaces K x raftcorr_lookup_bwd + zero fill + fold: the folded level-0 gradient is made in LDS and written once")
+    # the same step when d(out) arrives channels-last (a model run in torch.channels_last): the lookups' backward keeps
+    # views instead of launching the 12 transposition passes
+    saved = wl.gouts
+    wl.gouts = [g.contiguous(memory_format=torch.channels_last) for g in saved]
+    try:
+        for _ in range(3):
+            wl.step(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            wl.step(None)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        out["step_channels_last_dout"] = {"frame_pairs_per_sec": B / ms * 1e3, "ms_per_step": ms, "steps": n,
+                                          "note": "not the headline: BASELINE configs[3] hands d(out) over as contiguous NCHW"}
+    finally:
+        wl.gouts = saved
     prof = load_profile_json("r03_things_kernels.json") or load_profile_json("r02_things_kernels.json")
     psrc = "profiles/r03_things_kernels.json" if load_profile_json("r03_things_kernels.json") else "profiles/r02_things_kernels.json"
     for name, us in prof.items():                                # per-kernel durations from the committed trace

@@ -217,10 +217,24 @@ def _build(fmap1, fmap2, pyr, precision="fp32"):
     return flat
 
 
-def _record(pyr, mode, radius, coords, dout):
-    """Note a lookup's gradient for the deferred backward: fork-mode d(out) (B, N, C) is the record itself, canonical
-    d(out) (B, C, H, W) is transposed to (B, N, C) by raftcorr_lookup_bwd_record."""
-    if mode == _lib.MODE_FORK:
+def _channels_last_rows(dout):
+    """(B, N, C) view of a canonical d(out) (B, C, H, W) that sits in memory channels-last (what a model run in
+    torch.channels_last hands back): it IS the record, no transposition pass.  None for any other layout."""
+    if dout.dim() != 4 or dout.dtype is not torch.float32 or dout.is_contiguous():
+        return None
+    if not dout.is_contiguous(memory_format=torch.channels_last):
+        return None
+    B, C, H, W = dout.shape
+    return dout.permute(0, 2, 3, 1).reshape(B, H * W, C)        # a view: the permuted tensor is contiguous
+
+
+def _record(pyr, mode, radius, coords, dout, rows=None):
+    """Note a lookup's gradient for the deferred backward: fork-mode d(out) (B, N, C) is the record itself, so is a
+    channels-last canonical d(out) (`rows`); a canonical d(out) (B, C, H, W) is transposed to (B, N, C) by
+    raftcorr_lookup_bwd_record."""
+    if rows is not None:
+        rec = rows
+    elif mode == _lib.MODE_FORK:
         rec = dout
     else:
         B, C = dout.shape[:2]
@@ -326,9 +340,14 @@ class _Lookup(torch.autograd.Function):
         (coords,) = ctx.saved_tensors
         pyr = ctx.pyr
         lib = _lib.load()
-        dout = _f32c(dout)
         need_vol = ctx.needs_input_grad[0]
         need_co = ctx.needs_input_grad[1]
+        if need_vol and not need_co and ctx.mode != _lib.MODE_FORK and pyr.deferred:
+            rows = _channels_last_rows(dout)
+            if rows is not None and pyr.records_take(ctx.mode):
+                _record(pyr, ctx.mode, ctx.radius, coords, None, rows)
+                return None, None, None, None, None
+        dout = _f32c(dout)
         if need_co and pyr.vol:
             raise RuntimeError("CorrBlock: the gradient w.r.t. coords needs a float32 volume (volume_dtype='fp32'); "
                                "detach coords as core/raft.py:124 does")

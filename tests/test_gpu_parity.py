@@ -782,6 +782,35 @@ def test_deferred_backward_with_pyramid_gradient_and_both_conventions(dev):
     assert rel_err(d1, o1) <= GTOL and rel_err(d2, o2) <= GTOL
 
 
+def test_deferred_backward_takes_channels_last_gradients_by_reference(dev):
+    """A model run in torch.channels_last hands d(out) back as (B, C, H, W) with channels-last strides: that memory
+    is the (B, N, C) record already, so the lookup's backward keeps a view and launches nothing.  Same gradients, bit
+    for bit, as with contiguous d(out) (the transposition pass moves values, it does not compute)."""
+    from raft_amd import CorrBlock
+    import raft_amd.corr as C
+    rs = np.random.RandomState(5)
+    B, D, H, W, L, r, iters = 2, 32, 24, 40, 4, 4, 5
+    f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([xx, yy], 0)[None].repeat(B, 0).astype(np.float32)
+    coords = [torch.from_numpy(base + (k + 1) * 0.9 * rs.randn(B, 2, H, W).astype(np.float32)).to(dev) for k in range(iters)]
+    gouts = [torch.from_numpy(rs.randn(B, L * 81, H, W).astype(np.float32)).to(dev) for _ in range(iters)]
+
+    def run(gs):
+        f1 = torch.from_numpy(f1n).to(dev).requires_grad_(True)
+        f2 = torch.from_numpy(f2n).to(dev).requires_grad_(True)
+        cb = CorrBlock(f1, f2, num_levels=L, radius=r, backward="deferred")
+        torch.autograd.backward([cb(c) for c in coords], gs)
+        return f1.grad, f2.grad
+
+    a1, a2 = run(gouts)
+    cl = [g.contiguous(memory_format=torch.channels_last) for g in gouts]
+    assert all(C._channels_last_rows(g) is not None for g in cl) and all(C._channels_last_rows(g) is None for g in gouts)
+    assert C._channels_last_rows(cl[0]).data_ptr() == cl[0].data_ptr()               # a view, not a copy
+    b1, b2 = run(cl)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+
+
 def test_lookup_bwd_record_is_a_transposition(dev):
     """raftcorr_lookup_bwd_record through the C ABI: (B, C, H, W) -> (B, H*W, C), bit for bit, ragged query blocks,
     channel counts below and above the whole-row tile (384)."""
