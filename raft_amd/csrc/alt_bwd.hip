@@ -136,7 +136,8 @@ void alt_pack_tiles_kernel(PackSet ps)
 // ---------------------------------------------------------------------------------------------
 // Window mode: query groups by window position, deterministic.  The queries are dealt into buckets by the 8x8 cell of
 // level-0 targets that holds their window centre (one ring of cells around the map takes the centres outside it);
-// every 64 queries of a bucket, IN QUERY ORDER, form a group, groups are numbered in bucket order.  Three small
+// the buckets of a row of cells are laid end to end, queries IN QUERY ORDER inside a bucket, and every 64 slots form a
+// group (a row starts a new group).  Three small
 // launches: count (one wave per bucket scans the coordinates), scan (groups per bucket -> first group), fill (the same
 // scan as the count, ordered compaction by ballot + popcount).  No atomics: the lists depend on the coordinates only,
 // so the backward pass stays bit-reproducible.  Under smooth flow a bucket is a pixel tile; under per-pixel noise the
@@ -145,7 +146,7 @@ struct WSortArgs {
     const float* coords;                          // (B, 2, H, W)
     int* cnt;                                     // [B][nb][nch] queries of chunk ch in the bucket; after the scan: the
                                                   // bucket's queries in the chunks before ch
-    int* toff;                                    // [B][nb] first group of the bucket
+    int* toff;                                    // [B][nb] first slot of the bucket in qlist (rows of cells end to end)
     int* ngr;                                     // [B] groups in use
     int* qlist;                                   // [B][gmax][64]
     int N, nbx, nby, nb, nch, gmax;
@@ -163,8 +164,11 @@ __device__ __forceinline__ int wbucket_key(const WSortArgs& p, float x, float y)
 }
 
 // One wave per (bucket, chunk of WCHUNK consecutive queries).  FILL = false: cnt[b][bucket][chunk]; FILL = true: the
-// chunk's queries of the bucket -> qlist behind those of the earlier chunks (ordered compaction by ballot + popcount),
-// the bucket's last group padded with -1 by its last chunk.  grid (nb, nch, B), block 64
+// chunk's queries of the bucket -> qlist behind those of the earlier chunks (ordered compaction by ballot + popcount).
+// The buckets of one ROW of cells are laid end to end (toff = first SLOT of the bucket), so a group of 64 may hold the
+// tail of one cell and the head of its right neighbour: under per-pixel noise a cell holds 30..40 queries, and groups
+// that stop at cell borders would be half empty (KITTI random walks: 230..250 groups for 115 full ones).  A row's
+// last group is padded with -1 by the row's last bucket.  grid (nb, nch, B), block 64
 template <bool FILL>
 __global__ __launch_bounds__(64)
 void alt_wbucket_kernel(WSortArgs p)
@@ -173,7 +177,7 @@ void alt_wbucket_kernel(WSortArgs p)
     const float* __restrict__ cx = p.coords + (size_t)b * 2 * p.N;
     const int slot = (b * p.nb + bucket) * p.nch + ch;
     int n = FILL ? p.cnt[slot] : 0;               // wave-uniform: position inside the bucket / count
-    int* __restrict__ list = FILL ? p.qlist + ((size_t)b * p.gmax + p.toff[b * p.nb + bucket]) * 64 : nullptr;
+    int* __restrict__ list = FILL ? p.qlist + (size_t)b * p.gmax * 64 + p.toff[b * p.nb + bucket] : nullptr;
     const int qa = ch * WCHUNK;
     float x[WCHUNK / 64], y[WCHUNK / 64];
 #pragma unroll
@@ -190,39 +194,40 @@ void alt_wbucket_kernel(WSortArgs p)
         n += __popcll(m);
     }
     if (!FILL) { if (lane == 0) p.cnt[slot] = n; return; }
-    if (ch == p.nch - 1 && (n & 63) && lane >= (n & 63)) list[(n & ~63) + lane] = -1;
+    if (ch == p.nch - 1 && bucket % p.nbx == p.nbx - 1) {            // end of the row: pad its last group
+        const int end = p.toff[b * p.nb + bucket] + n;               // (n = the whole bucket now)
+        if ((end & 63) && lane >= (end & 63)) p.qlist[(size_t)b * p.gmax * 64 + (end & ~63) + lane] = -1;
+    }
 }
 
-// groups per bucket -> first group of every bucket, groups in use; cnt becomes the exclusive prefix over a bucket's
-// chunks.  grid (B), block 1024
+// queries per bucket -> first slot of every bucket (rows of cells end to end, every row starting a new group), groups
+// in use; cnt becomes the exclusive prefix over a bucket's chunks.  grid (B), block 1024
 __global__ __launch_bounds__(1024)
 void alt_wscan_kernel(WSortArgs p)
 {
-    __shared__ int wsum[16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int rowbase[1024];                 // first group of a row of cells (nby <= 1024: checked by the launcher)
+    const int b = blockIdx.x, tid = threadIdx.x;
     int* __restrict__ cnt = p.cnt + (size_t)b * p.nb * p.nch;
     int* __restrict__ off = p.toff + b * p.nb;
-    const int per = (p.nb + 1023) / 1024, i0 = min(tid * per, p.nb), i1 = min(i0 + per, p.nb);
-    int local = 0;
-    for (int i = i0; i < i1; ++i) {
+    for (int i = tid; i < p.nb; i += 1024) {
         int tot = 0;
         for (int c = 0; c < p.nch; ++c) { const int v = cnt[i * p.nch + c]; cnt[i * p.nch + c] = tot; tot += v; }
-        off[i] = (tot + 63) >> 6;                            // groups of the bucket, replaced by its first group below
-        local += off[i];
+        off[i] = tot;                                        // queries of the bucket, replaced by its first slot below
     }
-    int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int run = incl - local, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; run += w < wave ? v : 0; total += v; }
-    for (int i = i0; i < i1; ++i) { const int groups = off[i]; off[i] = run; run += groups; }
-    if (tid == 0) p.ngr[b] = total;
+    if (tid < p.nby) {                                       // one thread per row of cells: prefix inside the row
+        int run = 0;
+        for (int i = tid * p.nbx; i < (tid + 1) * p.nbx; ++i) { const int v = off[i]; off[i] = run; run += v; }
+        rowbase[tid] = (run + 63) >> 6;                      // groups of the row
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int r = 0; r < p.nby; ++r) { const int g = rowbase[r]; rowbase[r] = run; run += g; }
+        p.ngr[b] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < p.nb; i += 1024) off[i] += rowbase[i / p.nbx] * 64;
 }
 
 // tile-major copy of fmap1 for the groups (the partner images of the d(fmap2) role), gathered from the forward
@@ -911,6 +916,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc;
     if (window) {
+        if (pl.nby > 1024) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd_sorted: H = %d (more than 1024 rows of 8x8 cells)", H);
         WSortArgs w = {};
         w.coords = coords; w.N = H * W; w.nbx = pl.nbx; w.nby = pl.nby; w.nb = pl.nb; w.nch = pl.nch; w.gmax = pl.qtiles;
         w.cnt = (int*)((char*)workspace + pl.off_cnt); w.toff = (int*)((char*)workspace + pl.off_toff);
