@@ -262,12 +262,14 @@ int raftcorr_alt_lookup_fwd(const void* packed1, const void* const* packed2_leve
                             const float* coords, float* out, void* stream);
 
 /* raftcorr_alt_lookup_fwd with the query tiles formed by WINDOW position instead of pixel position: same arguments,
- * same results up to the last bit of a sum, also from run to run (a query's taps do not depend on which queries share
- * its tile, but the tile's box does, and a window split over two passes of a box adds its halves in another order;
- * tile membership follows the order of the bucket kernel's atomics), one more small launch.
+ * same results up to the last bit of a sum (a query's taps do not depend on which queries share its tile, but the
+ * tile's box does, and a window split over two passes of a box adds its halves in another order).
  * A pixel tile's cost grows with the disagreement of its 64 flow vectors (the product covers the bounding box of their
- * windows); tiles of queries whose window centres share an 8x8 target cell cost the same for any flow field.
- * workspace: raftcorr_alt_lookup_fwd_sorted_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care. */
+ * windows); tiles of queries whose windows start in the same row of 8x8 target cells, neighbours in that row, cost
+ * the same for any flow field.  The tiles ("groups") are built by three small launches without atomics -- they are a
+ * function of the coordinates alone, so the call is bit-reproducible -- and are left in the workspace:
+ * raftcorr_alt_lookup_bwd_sorted takes them as `groups` for the same coordinates instead of building them again.
+ * workspace: raftcorr_alt_lookup_fwd_sorted_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care before. */
 int64_t raftcorr_alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int num_levels);
 int raftcorr_alt_lookup_fwd_sorted(const void* packed1, const void* const* packed2_levels, const float* scales,
                                    int B, int H, int W, int C, int num_levels, int radius,
@@ -306,16 +308,18 @@ int raftcorr_alt_lookup_bwd(const void* tiles1, const void* const* tiles2_levels
  * raftcorr_alt_lookup_fwd_sorted (no reference line: the reference's kernel works pixel by pixel).  Same arguments and
  * results as raftcorr_alt_lookup_bwd (to the order of the fp32 sums), except packed1: the FORWARD pass' packed copy of
  * fmap1 (raftcorr_alt_pack) instead of the tile-major one -- the tile-major partner images are gathered per call for
- * the query groups.  The groups are a function of the coordinates alone (buckets by the 8x8 level-0 cell of the window
- * centre, members in query order, no atomics), so the results are bit-reproducible like the pixel-tile call's.  A pixel
- * tile's cost grows with the disagreement of its 64 flow vectors; a group's does not.  Four more small launches per
- * call: choose it when the flow is rough.  workspace: raftcorr_alt_lookup_bwd_sorted_workspace_bytes(...). */
+ * the query groups -- and groups: the workspace of raftcorr_alt_lookup_fwd_sorted as that call left it for the SAME
+ * coords (B, H, W), or NULL (the groups are then built here: three more small launches).  The groups are a function
+ * of the coordinates alone (cells in raster order, members in query order, no atomics), so the results are
+ * bit-reproducible like the pixel-tile call's.  A pixel tile's cost grows with the disagreement of its 64 flow
+ * vectors; a group's does not: choose it when the flow is rough.
+ * workspace: raftcorr_alt_lookup_bwd_sorted_workspace_bytes(...). */
 int64_t raftcorr_alt_lookup_bwd_sorted_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius);
 int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles2_levels, const float* scales,
                                    int B, int H, int W, int C, int num_levels, int radius,
                                    const float* coords, const float* dout,
                                    float* dfmap1, float* const* dfmap2_levels, int accumulate,
-                                   void* workspace, int64_t workspace_bytes, void* stream);
+                                   const void* groups, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Set-up and tear-down of one frame pair of the on-the-fly block, one host call each (what core/corr.py:64-73 does in
  * its constructor -- the avg_pool2d chain -- plus the packed copies the kernels above read; and its adjoint).

@@ -75,7 +75,7 @@ _SIGNATURES = {
                                  ctypes.c_void_p], _c_int),
     "raftcorr_alt_lookup_bwd_sorted_workspace_bytes": ([_c_int] * 6, ctypes.c_int64),
     "raftcorr_alt_lookup_bwd_sorted": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
-                                       [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_fp, ctypes.c_int64,
+                                       [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_fp, _c_fp, ctypes.c_int64,
                                         ctypes.c_void_p], _c_int),
     "raftcorr_alt_prepare_workspace_bytes": ([_c_int] * 5, ctypes.c_int64),
     "raftcorr_alt_prepare": ([_c_fp, _c_fp] + [_c_int] * 5 + [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp,

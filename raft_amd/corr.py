@@ -587,26 +587,33 @@ def _pack_conv_weight(lib, weight, cout, cin):
     return packed
 
 
-def _alt_forward(blk, coords):
-    """raftcorr_alt_lookup_fwd on the block's packed features (all levels, one launch)."""
+def _alt_forward(blk, coords, keep_groups=False):
+    """raftcorr_alt_lookup_fwd on the block's packed features (all levels, one launch).  Window mode builds the
+    lookup's query groups in front; keep_groups: into a buffer of its own, returned for the backward pass (else into
+    the block's reusable one)."""
     lib = _lib.load()
     B, C, H, W = blk._shape
     L = blk.num_levels
     out = torch.empty(B, L * (2 * blk.radius + 1) ** 2, H, W, dtype=torch.float32, device=coords.device)
+    groups = None
     with _guard(coords):
         if blk.tiles == "window":
-            if blk._sort_work is None:
+            if keep_groups or blk._sort_work is None:
                 nbytes = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, L)
-                blk._sort_work = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+                groups = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+                if not keep_groups:
+                    blk._sort_work = groups
+            if not keep_groups:
+                groups = blk._sort_work
             _lib.check(lib.raftcorr_alt_lookup_fwd_sorted(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
                                                           blk.radius, coords.data_ptr(), out.data_ptr(),
-                                                          blk._sort_work.data_ptr(), blk._sort_work.numel(), _stream(coords)),
+                                                          groups.data_ptr(), groups.numel(), _stream(coords)),
                        "alt_lookup_fwd_sorted")
         else:
             _lib.check(lib.raftcorr_alt_lookup_fwd(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
                                                    blk.radius, coords.data_ptr(), out.data_ptr(), _stream(coords)),
                        "alt_lookup_fwd")
-    return out
+    return (out, groups) if keep_groups else out
 
 
 class _AltGradState:
@@ -675,7 +682,9 @@ class _AltLookup(torch.autograd.Function):
     def forward(ctx, anchor, coords, blk):
         ctx.blk = blk
         ctx.save_for_backward(coords)
-        return _alt_forward(blk, coords)
+        # window mode: the lookup's query groups (a few hundred KB) stay alive for its backward pass
+        out, ctx.groups = _alt_forward(blk, coords, keep_groups=True)
+        return out
 
     @staticmethod
     @once_differentiable
@@ -693,8 +702,10 @@ class _AltLookup(torch.autograd.Function):
                 _lib.check(lib.raftcorr_alt_lookup_bwd_sorted(blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W,
                                                               C, L, blk.radius, coords.data_ptr(), dout.data_ptr(),
                                                               acc[0].data_ptr(), blk._gstate.ptrs, 0 if first else 1,
+                                                              ctx.groups.data_ptr() if ctx.groups is not None else None,
                                                               work.data_ptr(), work.numel(), _stream(coords)),
                            "alt_lookup_bwd_sorted")
+                ctx.groups = None
             else:
                 _lib.check(lib.raftcorr_alt_lookup_bwd(blk._t1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
                                                        blk.radius, coords.data_ptr(), dout.data_ptr(),

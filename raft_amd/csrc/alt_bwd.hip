@@ -795,8 +795,8 @@ struct BwdPlan {
     size_t off_boxes, off_wins, off_partial, bytes;
     bool any_split;
     // window mode
-    int nbx, nby, nb, nch;
-    size_t off_cnt, off_toff, off_ngr, off_qlist, off_dg, off_f1g;
+    AltGroupsPlan gp;
+    size_t off_groups, off_dg, off_f1g;
 };
 
 BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
@@ -807,10 +807,8 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
     const int ptiles = pl.qtx * ((H + QH - 1) / QH);         // 8x8 pixel tiles
     pl.qtiles = ptiles;
     if (window) {
-        // buckets = 8x8 cells of level-0 targets + one ring; group slots: every bucket may end in a partly filled group
-        pl.nbx = ((W + 7) >> 3) + 2; pl.nby = ((H + 7) >> 3) + 2; pl.nb = pl.nbx * pl.nby;
-        pl.qtiles = (H * W + TQ - 1) / TQ + pl.nb;
-        pl.nch = (H * W + WCHUNK - 1) / WCHUNK;
+        pl.gp = alt_groups_plan(B, H, W);
+        pl.qtiles = pl.gp.gmax;
     }
     // Channels per workgroup.  GW: the G image of a step is built once and multiplied with two partner slices (half the
     // construction work, the kernel's bottleneck) -- when the query tiles alone fill the chip; with few tiles (KITTI at
@@ -839,10 +837,7 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
     size_t end = up(pl.off_partial + pf * sizeof(float));
     if (window) {
         const int rd2 = (2 * r + 1) * (2 * r + 1);
-        pl.off_cnt = end;    end = up(end + sizeof(int) * (size_t)B * pl.nb * pl.nch);
-        pl.off_toff = end;   end = up(end + sizeof(int) * (size_t)B * pl.nb);
-        pl.off_ngr = end;    end = up(end + sizeof(int) * (size_t)B);
-        pl.off_qlist = end;  end = up(end + sizeof(int) * (size_t)B * pl.qtiles * TQ);
+        pl.off_groups = end; end = up(end + pl.gp.bytes);      // (used when the caller brings no groups of its own)
         pl.off_dg = end;     end = up(end + sizeof(float) * (size_t)B * L * pl.qtiles * rd2 * TQ);
         pl.off_f1g = end;    end = up(end + (size_t)B * pl.qtiles * pl.Cp * 256);
     }
@@ -851,6 +846,45 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
 }
 
 }  // namespace
+
+// buckets = 8x8 cells of level-0 targets + one ring; group slots: every row of cells may end in a partly filled group
+AltGroupsPlan alt_groups_plan(int B, int H, int W)
+{
+    AltGroupsPlan g = {};
+    g.nbx = ((W + 7) >> 3) + 2; g.nby = ((H + 7) >> 3) + 2; g.nb = g.nbx * g.nby;
+    g.nch = (H * W + WCHUNK - 1) / WCHUNK;
+    g.gmax = (H * W + TQ - 1) / TQ + g.nb;
+    auto up = [](size_t n) { return (n + 255) / 256 * 256; };
+    g.off_qlist = up(sizeof(int) * (size_t)B);
+    g.off_toff = up(g.off_qlist + sizeof(int) * (size_t)B * g.gmax * TQ);
+    g.off_cnt = up(g.off_toff + sizeof(int) * (size_t)B * g.nb);
+    g.bytes = up(g.off_cnt + sizeof(int) * (size_t)B * g.nb * g.nch);
+    return g;
+}
+
+// count / scan / fill: the groups of `coords` -> groups[0 .. B) = groups in use, qlist behind them
+int launch_alt_groups(const float* coords, int B, int H, int W, void* groups, size_t groups_bytes, hipStream_t s)
+{
+    const AltGroupsPlan g = alt_groups_plan(B, H, W);
+    if (!groups || groups_bytes < g.bytes)
+        return fail(RAFTCORR_EINVAL, "alt groups: buffer of %zu bytes needed, %zu given", g.bytes, groups_bytes);
+    if (((uintptr_t)groups & 255) != 0) return fail(RAFTCORR_EINVAL, "alt groups: the buffer must be 256-byte aligned");
+    if (g.nby > 1024 || g.nb > 65535 || g.nch > 65535 || B > 65535 || (size_t)H * W >= ((size_t)1 << 30))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt groups: %d x %d x %d is too large", B, H, W);
+    WSortArgs w = {};
+    w.coords = coords; w.N = H * W; w.nbx = g.nbx; w.nby = g.nby; w.nb = g.nb; w.nch = g.nch; w.gmax = g.gmax;
+    w.ngr = (int*)groups;
+    w.qlist = (int*)((char*)groups + g.off_qlist);
+    w.toff = (int*)((char*)groups + g.off_toff);
+    w.cnt = (int*)((char*)groups + g.off_cnt);
+    int rc;
+    hipLaunchKernelGGL(alt_wbucket_kernel<false>, dim3(g.nb, g.nch, B), dim3(64), 0, s, w);
+    if ((rc = check_launch("alt_wbucket_kernel<count>"))) return rc;
+    hipLaunchKernelGGL(alt_wscan_kernel, dim3(B), dim3(1024), 0, s, w);
+    if ((rc = check_launch("alt_wscan_kernel"))) return rc;
+    hipLaunchKernelGGL(alt_wbucket_kernel<true>, dim3(g.nb, g.nch, B), dim3(64), 0, s, w);
+    return check_launch("alt_wbucket_kernel<fill>");
+}
 
 size_t alt_tiles_bytes(int B, int C, int H, int W)
 {
@@ -882,10 +916,11 @@ size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, 
 }
 
 // f1p_window != nullptr selects window mode: f1t is ignored, the tile-major partner images of fmap1 are gathered per
-// call for the query groups from the forward pass' packed copy f1p_window
+// call for the query groups from the forward pass' packed copy f1p_window.  groups: the group buffer of the same
+// coordinates as launch_alt_groups left it (the forward pass of the lookup builds one), or nullptr: built here
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window)
+                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window, const void* groups)
 {
     if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: radius %d > 7", r);
     const bool window = f1p_window != nullptr;
@@ -894,7 +929,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
         return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace of %zu bytes needed, %zu given", pl.bytes, workspace_bytes);
     if (((uintptr_t)workspace & 255) != 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace must be 256-byte aligned");
     if ((long long)pl.seg[L] <= 0 || (size_t)B * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31) ||
-        (window && ((size_t)H * W * (pl.Cp / 32) * 8 >= ((size_t)1 << 31) || pl.nb > 65535 || pl.nch > 65535 ||
+        (window && ((size_t)H * W * (pl.Cp / 32) * 8 >= ((size_t)1 << 31) ||
                     (size_t)B * L * pl.qtiles * (2 * r + 1) * (2 * r + 1) * TQ >= ((size_t)1 << 31))))
         return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
     AltBwdArgs a = {};
@@ -916,18 +951,15 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc;
     if (window) {
-        if (pl.nby > 1024) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd_sorted: H = %d (more than 1024 rows of 8x8 cells)", H);
-        WSortArgs w = {};
-        w.coords = coords; w.N = H * W; w.nbx = pl.nbx; w.nby = pl.nby; w.nb = pl.nb; w.nch = pl.nch; w.gmax = pl.qtiles;
-        w.cnt = (int*)((char*)workspace + pl.off_cnt); w.toff = (int*)((char*)workspace + pl.off_toff);
-        w.ngr = (int*)((char*)workspace + pl.off_ngr); w.qlist = (int*)((char*)workspace + pl.off_qlist);
-        hipLaunchKernelGGL(alt_wbucket_kernel<false>, dim3(pl.nb, pl.nch, B), dim3(64), 0, s, w);
-        if ((rc = check_launch("alt_wbucket_kernel<count>"))) return rc;
-        hipLaunchKernelGGL(alt_wscan_kernel, dim3(B), dim3(1024), 0, s, w);
-        if ((rc = check_launch("alt_wscan_kernel"))) return rc;
-        hipLaunchKernelGGL(alt_wbucket_kernel<true>, dim3(pl.nb, pl.nch, B), dim3(64), 0, s, w);
-        if ((rc = check_launch("alt_wbucket_kernel<fill>"))) return rc;
-        a.qlist = w.qlist; a.ngr = w.ngr;
+        if (!groups) {
+            void* own = (char*)workspace + pl.off_groups;
+            if ((rc = launch_alt_groups(coords, B, H, W, own, pl.gp.bytes, s))) return rc;
+            groups = own;
+        } else if (((uintptr_t)groups & 255) != 0) {
+            return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: groups must be 256-byte aligned");
+        }
+        a.ngr = (int*)groups;
+        a.qlist = (int*)((char*)groups + pl.gp.off_qlist);
         a.dg = (float*)((char*)workspace + pl.off_dg);
         uint4* f1g = (uint4*)((char*)workspace + pl.off_f1g);
         a.f1t = f1g;

@@ -47,11 +47,11 @@ struct AltFwdArgs {
     int B, C, Cp, H, W, L, r;
     int band;                                     // tiles per XCD band
     float sqrt_c;
-    // sorted mode (qlist != nullptr): the tiles are lists of 64 queries whose windows lie close together at the level
-    int* qlist;                                   // [B][nseg][tbtot][64] query pixel indices, -1 = empty slot
-    int* ntiles;                                  // [B][nseg][L] tiles in use
-    int loff[RAFTCORR_MAX_LEVELS];                // first tile of level l inside a segment's tbtot tiles
-    int tbtot, nseg, segn;                        // segments of segn queries (<= SEGQ) are bucketed on their own
+    // window mode (qlist != nullptr): the tiles are the query groups of launch_alt_groups (alt_bwd.hip), the same
+    // list for every level
+    const int* qlist;                             // [B][gmax][64] query pixel indices, -1 = empty slot
+    const int* ntiles;                            // [B] groups in use
+    int gmax;
 };
 
 struct TileSh : TileQ {
@@ -96,108 +96,12 @@ void alt_pack16_kernel(PackSet ps)
 // ---------------------------------------------------------------------------------------------
 // Query tiles by WINDOW position instead of pixel position.  A pixel tile's box is the bounding box of its 64 windows:
 // 18 x 18 targets at level 0 when the flow is smooth, but it grows with every pixel of disagreement between neighbours
-// (37 x 37 for per-pixel noise of sigma = 4), and the product covers the whole box for all 64 queries.  Here the queries
-// of a level are dealt into buckets by the cell of max(8 >> l, 1)^2 targets that holds their window centre (what an
-// 8 x 8 pixel tile covers at level l when the flow is smooth; one ring of cells around the map takes the centres outside
-// it), and every 64 queries of a bucket form a tile: its box is at most (cell + 2r + 1)^2 whatever the flow.
-// One workgroup per (level, segment of <= SEGQ queries, batch item), one query batch per thread: count (LDS atomics;
-// one per wave where all 64 pixels share the bucket), scan of the tiles per bucket, fill.  The order inside a bucket is
-// whatever the atomics give: a query's samples do not depend on its row in the tile or on its tile mates (the split of
-// a window over the passes of a large box can move the last bit of a sum).
-// grid (L, nseg, B), block 1024, dynamic LDS: (2 nb + 16) ints, nb = buckets of the largest level
-constexpr int SEGQ = 8192, BUCKET_NB = SEGQ / 1024;
-
-__device__ __forceinline__ int bucket_cell_shift(int l) { return l < 3 ? 3 - l : 0; }
-
-__device__ __forceinline__ int wave_slot(int* cnt, int k, bool valid)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long live = __ballot(valid);
-    if (live == 0) return 0;                                 // wave-uniform
-    const int leader = __ffsll((long long)live) - 1;
-    const int kk = __shfl(k, leader);
-    if (__ballot(valid && k == kk) == live) {
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&cnt[kk], __popcll(live));
-        return __shfl(base, leader) + __popcll(live & ((1ull << lane) - 1));
-    }
-    return valid ? atomicAdd(&cnt[k], 1) : 0;
-}
-
-__global__ __launch_bounds__(1024)
-void alt_bucket_kernel(AltFwdArgs p)
-{
-    extern __shared__ int lds_i[];
-    constexpr int NB = BUCKET_NB;
-    const int l = blockIdx.x, seg = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Wl = p.wl[l], Hl = p.hl[l], cs = bucket_cell_shift(l);
-    const int nbx = ((Wl + (1 << cs) - 1) >> cs) + 2, nby = ((Hl + (1 << cs) - 1) >> cs) + 2, nb = nbx * nby;
-    int* cnt = lds_i;
-    int* off = lds_i + nb;
-    int* wsum = lds_i + 2 * nb;                              // [16] wave totals of the scan
-    for (int i = tid; i < nb; i += 1024) cnt[i] = 0;
-    const int N = p.H * p.W, qa = seg * p.segn, qe = min(qa + p.segn, N);
-    const float s = 1.0f / (float)(1 << l);
-    const float* __restrict__ cx = p.coords + (size_t)b * 2 * N;
-    int k[NB];
-    {
-        float x[NB], y[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int q = min(qa + tid + j * 1024, N - 1);
-            x[j] = cx[q]; y[j] = cx[N + q];
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int x0, y0;
-            float f;
-            split_coord(x[j] * s, x0, f);
-            split_coord(y[j] * s, y0, f);
-            k[j] = (min(max(y0 >> cs, -1), nby - 2) + 1) * nbx + min(max(x0 >> cs, -1), nbx - 2) + 1;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; ++j) wave_slot(cnt, k[j], qa + tid + j * 1024 < qe);
-    __syncthreads();
-    // exclusive scan of the tiles per bucket: thread = `per` consecutive buckets, wave scan by shuffles, 16 wave totals
-    const int per = (nb + 1023) / 1024, i0 = min(tid * per, nb), i1 = min(i0 + per, nb);
-    int local = 0;
-    for (int i = i0; i < i1; ++i) local += (cnt[i] + 63) >> 6;
-    int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int run = incl - local, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; run += w < wave ? v : 0; total += v; }
-    for (int i = i0; i < i1; ++i) { off[i] = run; run += (cnt[i] + 63) >> 6; }
-    const int sb = b * p.nseg + seg;
-    if (tid == 0) p.ntiles[sb * p.L + l] = total;
-    __syncthreads();
-    int* __restrict__ list = p.qlist + ((size_t)sb * p.tbtot + p.loff[l]) * 64;
-    for (int i = tid; i < nb; i += 1024) {                   // empty slots of every bucket's last tile
-        const int c = cnt[i];
-        if (c & 63) {
-            int* tail = list + (size_t)(off[i] + (c >> 6)) * 64;
-            for (int j = c & 63; j < 64; ++j) tail[j] = -1;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < nb; i += 1024) cnt[i] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int q = qa + tid + j * 1024;
-        const bool valid = q < qe;
-        const int pos = wave_slot(cnt, k[j], valid);
-        if (valid) list[(size_t)(off[k[j]] + (pos >> 6)) * 64 + (pos & 63)] = q;
-    }
-}
+// (37 x 37 for per-pixel noise of sigma = 4), and the product covers the whole box for all 64 queries.  In window mode
+// the tiles are the query groups of launch_alt_groups (alt_bwd.hip: queries dealt by the 8 x 8 cell of level-0 targets
+// that holds their window origin, rows of cells laid end to end, 64 slots per group, built without atomics): at level
+// l the windows of a group lie 2^l times closer, so one list serves every level, and the lookup's backward pass
+// takes the same groups.  The lists are a function of the coordinates alone: window mode is bit-reproducible
+// (rounds 1-2 bucketed per level with LDS atomics; tile membership followed the order of the atomics).
 
 // ---------------------------------------------------------------------------------------------
 // forward.  grid: 8 XCD bands x (tiles per band x L x B), block 256 = 4 waves.
@@ -226,16 +130,15 @@ void alt_fwd16_kernel(AltFwdArgs p)
     const float mp1 = fmaxf(p.maxpart[threadIdx.x & 63], p.maxpart[(threadIdx.x & 63) + 64]);
     const float mp2 = fmaxf(p.maxpart[MAXPARTS16 + (threadIdx.x & 63)], p.maxpart[MAXPARTS16 + (threadIdx.x & 63) + 64]);
     Tile16 t;
-    if (p.qlist) {                                           // tiles = query lists of alt_bucket_kernel; bands as below
+    if (p.qlist) {                                           // tiles = query groups; bands as below
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, j = idx % p.band, bl = idx / p.band;
         t.l = bl % p.L;
-        const int sb = bl / p.L;                             // (batch item, segment)
-        t.b = sb / p.nseg;
-        const int nt = p.ntiles[sb * p.L + t.l], bandl = (nt + 7) >> 3, tile = xcd * bandl + j;
+        t.b = bl / p.L;
+        const int nt = p.ntiles[t.b], bandl = (nt + 7) >> 3, tile = xcd * bandl + j;
         t.live = j < bandl && tile < nt;
         if (!t.live) return;                                 // whole workgroup
         t.ty0 = t.tx0 = 0;
-        tile_level_setup(p, sh, t, p.qlist + ((size_t)sb * p.tbtot + p.loff[t.l] + tile) * 64);
+        tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.gmax + tile) * 64);
     } else {
         t = tile_setup16(p, sh);
         if (!t.live) return;
@@ -434,35 +337,10 @@ int launch_alt_pack(const float* fmap, int B, int C, int H, int W, const float* 
     return launch_alt_pack_set(&fmap, &H, &W, &maxpart, &packed, 1, B, C, s);
 }
 
-namespace {
-struct SortPlan { int loff[RAFTCORR_MAX_LEVELS], tbtot, tbmax, nbmax, nseg, segn; size_t off_list, bytes; };
-SortPlan make_sort_plan(int B, int H, int W, int L)
-{
-    SortPlan sp = {};
-    const long long N = (long long)H * W;
-    // segments of whole 8-row bands of the image where that fits (smooth flow: no bucket is cut in two by a segment border)
-    const int rows = (SEGQ / W) & ~7;
-    if (rows >= 8) sp.segn = rows * W;
-    else           sp.segn = (int)((N + (N + SEGQ - 1) / SEGQ - 1) / ((N + SEGQ - 1) / SEGQ));
-    if (sp.segn > N) sp.segn = (int)N;
-    sp.nseg = (int)((N + sp.segn - 1) / sp.segn);
-    const int nq = (sp.segn + 63) / 64;
-    for (int l = 0; l < L; ++l) {
-        const int cs = l < 3 ? 3 - l : 0, c = 1 << cs;
-        const int nb = ((((W >> l) + c - 1) >> cs) + 2) * ((((H >> l) + c - 1) >> cs) + 2);
-        sp.loff[l] = sp.tbtot;
-        sp.tbtot += nq + nb;                                 // every bucket may end in one partly filled tile
-        sp.tbmax = std::max(sp.tbmax, nq + nb);
-        sp.nbmax = std::max(sp.nbmax, nb);
-    }
-    sp.off_list = ((size_t)B * sp.nseg * L * sizeof(int) + 255) / 256 * 256;
-    sp.bytes = sp.off_list + (size_t)B * sp.nseg * sp.tbtot * 64 * sizeof(int);
-    return sp;
-}
-}  // namespace
+size_t alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int L) { (void)L; return alt_groups_plan(B, H, W).bytes; }
 
-size_t alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int L) { return make_sort_plan(B, H, W, L).bytes; }
-
+// workspace != nullptr: window mode.  The workspace is the lookup's group buffer: built here, and afterwards what the
+// lookup's backward pass (launch_alt_lookup_bwd16, `groups`) can take instead of building the same lists again
 int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, float* out, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
@@ -477,24 +355,19 @@ int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float
         return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_fwd: a packed map of %d x %d x %d exceeds 2^31 slots", H, W, C);
     const int tiles = ((W + QW - 1) / QW) * ((H + QH - 1) / QH);
     a.band = (tiles + 7) / 8;
-    if (workspace) {                                         // sorted mode: one more launch in front
-        const SortPlan sp = make_sort_plan(B, H, W, L);
-        if (workspace_bytes < sp.bytes)
-            return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: workspace of %zu bytes needed, %zu given", sp.bytes, workspace_bytes);
-        if (((uintptr_t)workspace & 255) != 0) return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: workspace must be 256-byte aligned");
-        if ((size_t)H * W >= ((size_t)1 << 30) || sp.nbmax > 7168 || B > 65535 || sp.nseg > 65535)
-            return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_fwd_sorted: %d x %d x %d is too large", B, H, W);
-        a.ntiles = (int*)workspace;
-        a.qlist = (int*)((char*)workspace + sp.off_list);
-        for (int l = 0; l < L; ++l) a.loff[l] = sp.loff[l];
-        a.tbtot = sp.tbtot; a.nseg = sp.nseg; a.segn = sp.segn;
-        a.band = (sp.tbmax + 7) / 8;
-        hipLaunchKernelGGL(alt_bucket_kernel, dim3(L, sp.nseg, B), dim3(1024), (size_t)(2 * sp.nbmax + 16) * sizeof(int), s, a);
-        const int rc = check_launch("alt_bucket_kernel");
+    if (workspace) {                                         // window mode: the groups in front
+        const AltGroupsPlan gp = alt_groups_plan(B, H, W);
+        if (workspace_bytes < gp.bytes)
+            return fail(RAFTCORR_EINVAL, "alt_lookup_fwd_sorted: workspace of %zu bytes needed, %zu given", gp.bytes, workspace_bytes);
+        const int rc = launch_alt_groups(coords, B, H, W, workspace, workspace_bytes, s);
         if (rc) return rc;
+        a.ntiles = (const int*)workspace;
+        a.qlist = (const int*)((const char*)workspace + gp.off_qlist);
+        a.gmax = gp.gmax;
+        a.band = (gp.gmax + 7) / 8;
     }
     const size_t sm = std::max((size_t)2 * STG * sizeof(uint4), (size_t)TQ * LDS_S * sizeof(float));
-    const dim3 grid(8u * a.band * L * B * (workspace ? a.nseg : 1));
+    const dim3 grid(8u * a.band * L * B);
     static thread_local bool allowed[64][2] = {};            // >64 KiB of dynamic LDS: opt in once per device and kernel
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -465,7 +465,7 @@ int64_t raftcorr_alt_lookup_bwd_sorted_workspace_bytes(int B, int H, int W, int 
 int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles2_levels, const float* scales,
                                    int B, int H, int W, int C, int num_levels, int radius,
                                    const float* coords, const float* dout, float* dfmap1, float* const* dfmap2_levels,
-                                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream)
+                                   int accumulate, const void* groups, void* workspace, int64_t workspace_bytes, void* stream)
 {
     int rc = check_dims("alt_lookup_bwd_sorted", B, H, W);
     if (rc) return rc;
@@ -480,7 +480,7 @@ int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles
     }
     return launch_alt_lookup_bwd16(nullptr, tiles2_levels, scales, B, H, W, C, num_levels, radius, coords, dout, dfmap1,
                                    dfmap2_levels, accumulate, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
-                                   (hipStream_t)stream, packed1);
+                                   (hipStream_t)stream, packed1, groups);
 }
 
 int64_t raftcorr_alt_prepare_workspace_bytes(int B, int C, int H, int W, int num_levels)

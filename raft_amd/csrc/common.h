@@ -42,6 +42,15 @@ int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec,
 int launch_build_bwd_deferred(const float* f1, const float* f2, int B, int D, int H, int W, int L, int r, int mode,
                               int K, const float* const* coords, const float* const* records, const LevelSet* dlv,
                               float* df1, float* df2, void* workspace, size_t workspace_bytes, hipStream_t s);
+// Query groups by window position ("window tiles"), built without atomics by launch_alt_groups (alt_bwd.hip) and used by
+// the forward and the backward pass alike.  Buffer layout: [ngr: B ints][qlist: B x gmax x 64 ints][scratch].
+struct AltGroupsPlan {
+    int nbx, nby, nb, nch, gmax;
+    size_t off_qlist, off_toff, off_cnt, bytes;             // ngr sits at offset 0
+};
+AltGroupsPlan alt_groups_plan(int B, int H, int W);
+int launch_alt_groups(const float* coords, int B, int H, int W, void* groups, size_t groups_bytes, hipStream_t s);
+
 int launch_alt_level_fwd(const float* f1, const float* f2, const float* coords, float* corr,
                          int B, int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s);
 int launch_alt_level_bwd(const float* f1, const float* f2, const float* coords, const float* cg,
@@ -69,7 +78,8 @@ int launch_alt_features_bwd(const float* d1, const float* const* d2, int B, int 
                             float* df1, float* df2, hipStream_t s);
 int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
                             int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window = nullptr);
+                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window = nullptr,
+                            const void* groups = nullptr);
 
 // floor + fraction of a sampling coordinate, memory-safe for NaN / huge values: anything
 // that is not a sane pixel coordinate is pushed far outside the map (all taps read as zero).

@@ -961,8 +961,9 @@ def test_on_the_fly_window_tiles(shape, dev):
     """tiles="window" (raftcorr_alt_lookup_fwd_sorted: query tiles by window position) against tiles="pixel": same
     samples up to the last bit of a sum (a window split over two passes of a box adds its halves in another order),
     for smooth flow, per-pixel noise, coordinates far outside the map and non-finite ones; every output element
-    written (the output starts as NaN inside torch.empty's storage only by accident, so it is checked for finiteness);
-    more than one segment of 8192 queries at the larger shapes."""
+    written (the output starts as NaN inside torch.empty's storage only by accident, so it is checked for finiteness).
+    Since round 3 the tiles are the deterministic query groups the backward pass uses too (no atomics): two runs of
+    window mode agree bit for bit, also from a second block (fresh buffers)."""
     from raft_amd import AlternateCorrBlock
     B, D, H, W = shape
     rs = np.random.RandomState(H + W)
@@ -988,6 +989,8 @@ def test_on_the_fly_window_tiles(shape, dev):
             a, b = pix(c), win(c)
             assert torch.isfinite(b).all(), kind
             assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 1e-6, kind
+            again = AlternateCorrBlock(f1, f2, num_levels=L, radius=4, tiles="window")(c)
+            assert torch.equal(win(c), b) and torch.equal(again, b), kind
 
 
 def test_host_errors(dev):

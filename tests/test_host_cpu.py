@@ -82,7 +82,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.raftcorr_alt_prepare_workspace_bytes(1, 256, 47, 156, 9) == 0
     assert lib.raftcorr_alt_prepare(None, None, 1, 256, 47, 156, 4, None, None, None, None, None, None, 0, None) == -1
     assert lib.raftcorr_alt_features_bwd(8, some, 1, 8, 6, 8, 4, 8, 8, None) == -1      # level 3 of a 6x8 map is empty
-    assert lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(1, 47, 156, 4) > 4 * 4 * 64 * ((47 * 156 + 63) // 64)
+    assert lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(1, 47, 156, 4) > 4 * 64 * ((47 * 156 + 63) // 64)     # one list of groups for all levels
     assert lib.raftcorr_alt_lookup_fwd_sorted(8, some, 8, 1, 47, 156, 256, 4, 4, 8, 8, None, 0, None) == -1
     assert b"null" in lib.raftcorr_last_error()
     assert lib.raftcorr_alt_lookup_bwd(8, some, 8, 1, 47, 156, 256, 4, 4, 8, 8, 8, some, 0, None, 0, None) == -1

@@ -37,6 +37,20 @@ with torch.no_grad():
     for tag, c in (("identity", coords[0]), ("sigma3", coords[1]), ("sigma4.2", coords[2]), ("sigma6", coords[4])):
         res_w[tag] = round(bench.ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd_sorted(
             blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, D, L, R, c.data_ptr(), gout.data_ptr(),
-            d1.data_ptr(), dlv, int(os.environ.get('ACC', '0')), swork.data_ptr(), swb, st), reps=30, warm=5), 1)
+            d1.data_ptr(), dlv, int(os.environ.get('ACC', '0')), None, swork.data_ptr(), swb, st), reps=30, warm=5), 1)
+    # with the groups of the forward pass: the backward call skips its own count / scan / fill
+    gb = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, L)
+    groups = torch.empty(gb, dtype=torch.uint8, device=dev)
+    o = torch.empty(B, L * (2 * R + 1) ** 2, H, W, device=dev)
+    res_g, res_f = {}, {}
+    for tag, c in (("identity", coords[0]), ("sigma3", coords[1]), ("sigma4.2", coords[2]), ("sigma6", coords[4])):
+        fwd = lambda: lib.raftcorr_alt_lookup_fwd_sorted(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, L, R,
+                                                         c.data_ptr(), o.data_ptr(), groups.data_ptr(), gb, st)
+        res_f[tag] = round(bench.ev_time_us(torch, fwd, reps=30, warm=5), 1)
+        res_g[tag] = round(bench.ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd_sorted(
+            blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, D, L, R, c.data_ptr(), gout.data_ptr(),
+            d1.data_ptr(), dlv, int(os.environ.get('ACC', '0')), groups.data_ptr(), swork.data_ptr(), swb, st), reps=30, warm=5), 1)
+    print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt fwd, window groups, us:", res_f, flush=True)
+    print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt bwd, window groups brought by the caller, us:", res_g, flush=True)
 print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt bwd us:", res, flush=True)
 print(os.path.basename(_lib.LIB_PATH), f"{H}x{W} B={B} alt bwd, window groups, us:", res_w, flush=True)
