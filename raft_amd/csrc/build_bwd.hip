@@ -599,7 +599,13 @@ static int gemm_ksplit(int M, int N, int K, int batch)
 {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     int ksplit = 1;
-    while (tiles * ksplit < 512 && ksplit < 16 && K / (ksplit * 2) >= 256) ksplit *= 2;
+    // 512 resident workgroups fill the chip; a launch of 400+ runs as one round either way, and not splitting saves the
+    // partial planes and their reduction (Things B=6: 432 and 504 tiles, backward 1.233 -> 1.202 ms)
+    int target = 400;
+#if defined(RC_LAB)                    // tools/ only: workgroups below which K is split once more
+    if (const char* e = getenv("RC_KSPLIT_TARGET")) target = atoi(e);
+#endif
+    while (tiles * ksplit < target && ksplit < 16 && K / (ksplit * 2) >= 256) ksplit *= 2;
     return ksplit;
 }
 
