@@ -82,6 +82,38 @@ void corr_record_kernel(RecordArgs p)
     }
 }
 
+// The same transposition with ALL channels of 32 queries in one workgroup (C % 4 == 0, C <= 512): a thread loads four
+// consecutive channels of its query and writes them to LDS as one 16-byte slot of the query's row (row pitch an odd
+// number of slots: the 16 rows a quarter-wave writes fall on different banks), and the workgroup's part of the record
+// -- 32 complete rows, 32 * C floats -- goes out as ONE contiguous run (41 KB at C = 324) instead of 432-byte pieces.
+// grid (ceil(N / 32), B), block 256, dynamic LDS 32 * (C / 4 | 1) * 16 bytes; IT: channel quads per thread (8 IT >= C / 4)
+template <int IT>
+__global__ __launch_bounds__(256)
+void corr_record_rows_kernel(RecordArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 rows4[];   // [32][S4]
+    const int tid = threadIdx.x, q0 = blockIdx.x * 32, b = blockIdx.y;
+    const int C4 = p.C >> 2, S4 = C4 | 1, nq = min(32, p.N - q0);
+    const int qi = tid & 31, cg = tid >> 5;
+    const float* __restrict__ src = p.dout + (size_t)b * p.C * p.N + q0 + min(qi, nq - 1);
+    float4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {                                   // every load in flight before the first use
+        const int c = 4 * min(cg + 8 * i, C4 - 1);
+        v[i].x = src[(size_t)c * p.N]; v[i].y = src[(size_t)(c + 1) * p.N];
+        v[i].z = src[(size_t)(c + 2) * p.N]; v[i].w = src[(size_t)(c + 3) * p.N];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        if (cg + 8 * i < C4) rows4[qi * S4 + cg + 8 * i] = v[i];
+    __syncthreads();
+    float4* __restrict__ dst = (float4*)(p.rec + ((size_t)b * p.N + q0) * p.C);
+    for (int e = tid; e < nq * C4; e += 256) {
+        const int q = e / C4, c4 = e - q * C4;
+        dst[e] = rows4[q * S4 + c4];
+    }
+}
+
 struct DeferredArgs {
     const float* rec[DEF_MAXK];      // (B, N, C) each
     const float* coords[DEF_MAXK];   // canonical: (B, 2, H, W); fork: (B, N, 2)
@@ -377,6 +409,17 @@ int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec,
 {
     RecordArgs a;
     a.dout = dout; a.rec = rec; a.N = N; a.C = C;
+    if ((C & 3) == 0 && C <= 512 && ((uintptr_t)rec & 15) == 0) {     // whole rows per workgroup
+        a.CH = C;
+        const int it = ((C >> 2) + 7) / 8;
+        const dim3 grid((N + 31) / 32, B);
+        const size_t lds = (size_t)32 * ((C >> 2) | 1) * 16;
+        if (it <= 4)       hipLaunchKernelGGL(corr_record_rows_kernel<4>, grid, dim3(256), lds, s, a);
+        else if (it <= 7)  hipLaunchKernelGGL(corr_record_rows_kernel<7>, grid, dim3(256), lds, s, a);     // r = 3, 4 levels
+        else if (it <= 11) hipLaunchKernelGGL(corr_record_rows_kernel<11>, grid, dim3(256), lds, s, a);    // r = 4, 4 levels
+        else               hipLaunchKernelGGL(corr_record_rows_kernel<16>, grid, dim3(256), lds, s, a);
+        return check_launch("corr_record_rows_kernel");
+    }
     const int chunks = (C + 127) / 128;
     a.CH = std::min(128, ((C + chunks - 1) / chunks + 3) & ~3);
     const dim3 grid((N + 31) / 32, (C + a.CH - 1) / a.CH, B);
