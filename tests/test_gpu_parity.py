@@ -869,6 +869,43 @@ def test_on_the_fly_window_groups_backward_is_bit_reproducible(dev):
     assert rel_err(a1, p1) <= 2e-6 and rel_err(a2, p2) <= 2e-6
 
 
+def test_on_the_fly_backward_takes_the_forward_call_s_groups(dev):
+    """C ABI: raftcorr_alt_lookup_fwd_sorted leaves the lookup's query groups in its workspace; handed to
+    raftcorr_alt_lookup_bwd_sorted as `groups` they give the same bits as groups = NULL (the backward call then
+    builds the same lists itself) -- also for a 1080p-wide map, where the group builder takes its three-launch path
+    with more chunks -- and the forward output equals the pixel-tile call's to the last bit of a sum."""
+    from raft_amd import AlternateCorrBlock, _lib
+    lib = _lib.load()
+    for (B, D, H, W, L, r) in ((2, 64, 47, 78, 4, 4), (1, 32, 40, 240, 3, 3)):
+        rs = np.random.RandomState(H * W)
+        f1 = _t(rs.randn(B, D, H, W).astype(np.float32), dev, True)
+        f2 = _t(rs.randn(B, D, H, W).astype(np.float32), dev)
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        c = _t((np.stack([xx, yy], 0)[None] + 4.0 * rs.randn(B, 2, H, W)).astype(np.float32), dev)
+        go = _t(rs.randn(B, L * (2 * r + 1) ** 2, H, W).astype(np.float32), dev)
+        blk = AlternateCorrBlock(f1, f2, num_levels=L, radius=r)          # (f1 requires grad: the backward's packs exist)
+        st = torch.cuda.current_stream().cuda_stream
+        gb = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, L)
+        groups = torch.empty(gb, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, L * (2 * r + 1) ** 2, H, W, device=dev)
+        _lib.check(lib.raftcorr_alt_lookup_fwd_sorted(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, L, r,
+                                                      c.data_ptr(), out.data_ptr(), groups.data_ptr(), gb, st), "fwd_sorted")
+        with torch.no_grad():
+            assert rel_err(out.cpu().numpy(), blk(c).cpu().numpy()) <= 1e-6
+        wb = lib.raftcorr_alt_lookup_bwd_sorted_workspace_bytes(B, H, W, D, L, r)
+        res = []
+        for g in (groups.data_ptr(), None):
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            d1 = torch.full((B, H, W, D), float("nan"), device=dev)
+            d2 = [torch.full((B, H >> l, W >> l, D), float("nan"), device=dev) for l in range(L)]
+            _lib.check(lib.raftcorr_alt_lookup_bwd_sorted(blk._p1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, D, L, r,
+                                                          c.data_ptr(), go.data_ptr(), d1.data_ptr(), _lib.ptr_array(d2), 0, g,
+                                                          work.data_ptr(), wb, st), "bwd_sorted")
+            res.append([d1] + d2)
+        for a, b in zip(*res):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_on_the_fly_gradients_sum_in_place(dev):
     """The lookups of one AlternateCorrBlock add their feature gradients into shared sums inside the backward
     kernel (accumulate = 1) instead of handing autograd one dense gradient per lookup.  Same bits as the sum of the
