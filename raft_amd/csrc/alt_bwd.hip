@@ -58,8 +58,9 @@ struct AltBwdArgs {
     float* partial;                               // d(fmap2) partial tiles of the split levels
     long long poff[RAFTCORR_MAX_LEVELS];          // level l's offset in `partial` (floats)
     int nsplit[RAFTCORR_MAX_LEVELS];
-    int seg[RAFTCORR_MAX_LEVELS + 1];             // workgroups [0, seg[0]): d(fmap1); [seg[l], seg[l+1]): d(fmap2_l);
+    int seg[RAFTCORR_MAX_LEVELS + 1];             // workgroups [0, seg[0]): d(fmap1); [seg[i], seg[i+1]): d(fmap2_l), l = lorder[i];
                                                   // every segment is padded to a multiple of 8 (one share per XCD)
+    int lorder[RAFTCORR_MAX_LEVELS];              // the levels in launch order (long workgroups first, the shortest last)
     int B, C, Cp, H, W, L, r;
     int qtx, qtiles, ngroups;
     int gw;                                       // channels per workgroup: CG or GW (see make_plan)
@@ -230,15 +231,144 @@ void alt_wscan_kernel(WSortArgs p)
     for (int i = tid; i < p.nb; i += 1024) off[i] += rowbase[i / p.nbx] * 64;
 }
 
+// The same groups in ONE launch for maps of up to WS_MAXQ queries (every BASELINE shape but 1080p): one workgroup per
+// batch item keeps the whole count table in LDS -- cnt[chunk of 64 queries][bucket], 16 bits each -- so the three
+// passes above become three phases between barriers and two of the three launch latencies (5 us each at this size)
+// go away.  A wave owns every 16th chunk; inside a chunk the queries of one bucket are found by ballots over the
+// chunk's distinct keys, which gives the per-chunk counts and each query's rank among its chunk mates of that
+// bucket; the exclusive prefix over the chunks of a bucket, the rows of cells laid end to end and the row-end padding
+// are those of alt_wscan_kernel / alt_wbucket_kernel<true>: the lists are the same, bit for bit.
+// grid (B), block 1024, dynamic LDS = ws_small_lds(nch64, nb, nby)
+constexpr int WS_WAVES = 16, WS_MAXC = 8, WS_MAXQ = WS_WAVES * WS_MAXC * 64;
+
+__host__ __device__ inline size_t ws_small_lds(int nch64, int nb, int nby)
+{
+    return (((size_t)nch64 * nb * 2 + 15) & ~(size_t)15) + 8 * (size_t)WS_WAVES * nb + sizeof(int) * (2 * (size_t)nb + 2 * (size_t)nby);
+}
+
+// exclusive prefix of v over the lanes of a wave; total = the sum over all 64 lanes
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
+{
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    total = __shfl(inc, 63);
+    return inc - v;
+}
+
+__global__ __launch_bounds__(1024)
+void alt_wgroups_small_kernel(WSortArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch64 = (p.N + 63) >> 6, nb = p.nb;
+    unsigned short* __restrict__ cnt = (unsigned short*)wsm;                               // [nch64][nb]
+    unsigned long long* masks = (unsigned long long*)(wsm + (((size_t)nch64 * nb * 2 + 15) & ~(size_t)15));   // [16 waves][nb]
+    int* __restrict__ tot = (int*)(masks + (size_t)WS_WAVES * nb);                         // [nb] queries of the bucket
+    int* __restrict__ toffs = tot + nb;                                                    // [nb] first slot of the bucket
+    int* __restrict__ rowg = toffs + nb;                                                   // [nby] first group of the row
+    int* __restrict__ rowlen = rowg + p.nby;                                               // [nby] queries of the row
+    const float* __restrict__ cx = p.coords + (size_t)b * 2 * p.N;
+
+    float x[WS_MAXC], y[WS_MAXC];
+#pragma unroll
+    for (int u = 0; u < WS_MAXC; ++u) {                       // all loads of the wave in flight
+        const int q = min((wave + WS_WAVES * u) * 64 + lane, p.N - 1);
+        x[u] = cx[q]; y[u] = cx[p.N + q];
+    }
+    for (int i = tid; i < (nch64 * nb + 1) / 2; i += 1024) ((unsigned*)cnt)[i] = 0u;
+    for (int i = tid; i < WS_WAVES * nb; i += 1024) masks[i] = 0ull;
+    __syncthreads();
+
+    // phase 1: per-chunk counts and ranks.  The lanes of a chunk that share a bucket find each other through a 64-bit
+    // lane mask per bucket (this wave's own table, LDS atomic OR: the result does not depend on the order of the lanes),
+    // rank = set bits below the lane, count = all set bits; every lane clears the entry it used.
+    int key[WS_MAXC], rank[WS_MAXC];
+    unsigned long long* __restrict__ mask = masks + (size_t)wave * nb;
+#pragma unroll
+    for (int u = 0; u < WS_MAXC; ++u) {
+        const int chunk = wave + WS_WAVES * u, q = chunk * 64 + lane;
+        const bool valid = q < p.N;
+        key[u] = valid ? wbucket_key(p, x[u], y[u]) : 0;
+        rank[u] = 0;
+        if (valid) atomicOr(&mask[key[u]], 1ull << lane);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const unsigned long long m = mask[key[u]];
+            rank[u] = __popcll(m & ((1ull << lane) - 1));
+            if (rank[u] == 0) cnt[chunk * nb + key[u]] = (unsigned short)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) mask[key[u]] = 0ull;
+    }
+    __syncthreads();
+
+    // phase 2: exclusive prefix over the chunks of a bucket (eight table reads in flight per thread) ...
+    for (int k = tid; k < nb; k += 1024) {
+        int run = 0;
+        for (int c0 = 0; c0 < nch64; c0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = cnt[min(c0 + j, nch64 - 1) * nb + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < nch64) { cnt[(c0 + j) * nb + k] = (unsigned short)run; run += v[j]; }
+        }
+        tot[k] = run;
+    }
+    __syncthreads();
+    // ... the buckets of a row of cells end to end (one wave per row) ...
+    for (int r = wave; r < p.nby; r += WS_WAVES) {
+        int carry = 0;
+        for (int i0 = 0; i0 < p.nbx; i0 += 64) {
+            const int i = i0 + lane, v = i < p.nbx ? tot[r * p.nbx + i] : 0;
+            int sum;
+            const int ex = wave_excl_scan(v, lane, sum);
+            if (i < p.nbx) toffs[r * p.nbx + i] = carry + ex;
+            carry += sum;
+        }
+        if (lane == 0) rowlen[r] = carry;
+    }
+    __syncthreads();
+    // ... and every row starting a new group
+    if (wave == 0) {
+        int carry = 0;
+        for (int r0 = 0; r0 < p.nby; r0 += 64) {
+            const int r = r0 + lane, g = r < p.nby ? (rowlen[r] + 63) >> 6 : 0;
+            int sum;
+            const int ex = wave_excl_scan(g, lane, sum);
+            if (r < p.nby) rowg[r] = carry + ex;
+            carry += sum;
+        }
+        if (lane == 0) p.ngr[b] = carry;
+    }
+    __syncthreads();
+
+    // phase 3: every query to its slot; the last group of a row padded with -1
+    int* __restrict__ ql = p.qlist + (size_t)b * p.gmax * 64;
+#pragma unroll
+    for (int u = 0; u < WS_MAXC; ++u) {
+        const int chunk = wave + WS_WAVES * u, q = chunk * 64 + lane;
+        if (q < p.N) {
+            const int k = key[u];
+            ql[rowg[k / p.nbx] * 64 + toffs[k] + cnt[chunk * nb + k] + rank[u]] = q;
+        }
+    }
+    for (int r = wave; r < p.nby; r += WS_WAVES) {
+        const int end = rowg[r] * 64 + rowlen[r];
+        if ((end & 63) && lane >= (end & 63)) ql[(end & ~63) + lane] = -1;
+    }
+}
+
 // tile-major copy of fmap1 for the groups (the partner images of the d(fmap2) role), gathered from the forward
 // pass' packed copy [pixel][Cp/32][hi: 4 slots of 8 channels | lo: 4 slots] (alt_fwd16.hip; same scaling).
-// grid (qtiles, Cp / 32, B), block 256
-__global__ __launch_bounds__(256)
-void alt_wgather_f1_kernel(const uint4* __restrict__ f1p, uint4* __restrict__ f1g, const int* __restrict__ qlist,
-                           const int* __restrict__ ngr, int qtiles, int Cp, size_t P)
+// One workgroup of 256 threads per (group g, 32-channel chunk, batch item); lines: TQ * 8 slots of LDS
+__device__ __forceinline__ void wgather_f1(const uint4* __restrict__ f1p, uint4* __restrict__ f1g, const int* __restrict__ qlist,
+                                           const int* __restrict__ ngr, int qtiles, int Cp, size_t P, int g, int chunk, int b,
+                                           uint4* lines)
 {
-    __shared__ uint4 lines[TQ * 8];               // [query][slot]: the queries' 128-byte lines of this channel chunk
-    const int g = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, nkc = Cp / 32;
+    const int tid = threadIdx.x, nkc = Cp / 32;
     if (g >= ngr[b]) return;
     const int* __restrict__ ql = qlist + ((size_t)b * qtiles + g) * TQ;
 #pragma unroll
@@ -263,22 +393,32 @@ void alt_wgather_f1_kernel(const uint4* __restrict__ f1p, uint4* __restrict__ f1
 }
 
 // ---------------------------------------------------------------------------------------------
-// The two small passes in front of the main kernel, in one launch (they do not depend on each other):
-//   workgroups [0, B * L * qtiles): per (batch, level, query tile) the 64 windows (origin + fractions) and their bounding box;
-//   the DMAXP workgroups after them: partial maxima of |d(out)| (n floats), the range of the G images.
-// block 64
+// The small passes in front of the main kernel, in one launch (they do not depend on each other):
+//   workgroups [0, nwin = B * L * qtiles): per (batch, level, query tile) the 64 windows (origin + fractions), their
+//                        bounding box and, in window mode, the group's d(out) tile;
+//   the DMAXP workgroups after them: partial maxima of |d(out)| (n floats), the range of the G images;
+//   window mode, ngather more: the groups' tile-major copy of fmap1 (wgather_f1), one workgroup per (group, 32-channel
+//                        chunk, batch item).
+// block 64 (pixel tiles) or 256 (window mode)
 __global__ __launch_bounds__(256)
-void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)   // block 64 (pixel tiles) or 256 (window mode)
+void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n, const uint4* __restrict__ f1p)
 {
     __shared__ TileQ sh;
+    __shared__ uint4 lines[TQ * 8];               // wgather_f1: the queries' 128-byte lines of one channel chunk
+    __shared__ float red[4];
+    if ((int)blockIdx.x >= nwin + DMAXP) {
+        const int idx = blockIdx.x - nwin - DMAXP, nkc = p.Cp / 32;
+        wgather_f1(f1p, const_cast<uint4*>(p.f1t), p.qlist, p.ngr, p.qtiles, p.Cp, (size_t)p.H * p.W,
+                   idx % p.qtiles, (idx / p.qtiles) % nkc, idx / (p.qtiles * nkc), lines);
+        return;
+    }
     if ((int)blockIdx.x >= nwin) {
-        if (threadIdx.x >= 64) return;                       // (window mode launches 256 threads)
-        const int j = blockIdx.x - nwin, lane = threadIdx.x;
+        const int j = blockIdx.x - nwin, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
         const float* __restrict__ x = p.dout;
         float m = 0.f;
         const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;       // 16-byte loads when aligned
-        constexpr size_t STRIDE = (size_t)DMAXP * 64;
-        size_t i = (size_t)j * 64 + lane;
+        const size_t STRIDE = (size_t)DMAXP * nw * 64;
+        size_t i = ((size_t)j * nw + w) * 64 + lane;
         for (; i + 3 * STRIDE < n4; i += 4 * STRIDE) {                   // four loads in flight per thread
             float4 v[4];
 #pragma unroll
@@ -291,10 +431,15 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n)   // block 64 (pixel t
             const float4 v = ((const float4*)x)[i];
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
-        for (size_t t = n4 * 4 + (size_t)j * 64 + lane; t < n; t += STRIDE) m = fmaxf(m, fabsf(x[t]));
+        for (size_t t = n4 * 4 + ((size_t)j * nw + w) * 64 + lane; t < n; t += STRIDE) m = fmaxf(m, fabsf(x[t]));
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) const_cast<float*>(p.dmax)[j] = m;
+        if (lane == 0) red[w] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int u = 1; u < nw; ++u) m = fmaxf(m, red[u]);
+            const_cast<float*>(p.dmax)[j] = m;
+        }
         return;
     }
     const int tile = blockIdx.x % p.qtiles, bl = blockIdx.x / p.qtiles;
@@ -661,11 +806,12 @@ void alt_bwd_kernel(AltBwdArgs p)
     }
 
     // ---------------- d(fmap2_l): owner = target tile, partners = query tiles whose windows touch it ----------------
-    int l = 0;
-    while (l + 1 < p.L && wg >= p.seg[l + 1]) ++l;
+    int si = 0;
+    while (si + 1 < p.L && wg >= p.seg[si + 1]) ++si;
+    const int l = p.lorder[si];
     const int nsplit = p.nsplit[l];
     const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
-    int idx = banded(wg - p.seg[l], p.seg[l + 1] - p.seg[l]);
+    int idx = banded(wg - p.seg[si], p.seg[si + 1] - p.seg[si]);
     if (idx >= p.B * ttiles * nsplit * p.ngroups) return;    // padding of the segment (whole workgroup)
     const int g = idx % p.ngroups; idx /= p.ngroups;
     int s, tt;
@@ -793,6 +939,7 @@ struct BwdPlan {
     int nsplit[RAFTCORR_MAX_LEVELS], ttiles[RAFTCORR_MAX_LEVELS], seg[RAFTCORR_MAX_LEVELS + 1];
     size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
     size_t off_boxes, off_wins, off_partial, bytes;
+    int lorder[RAFTCORR_MAX_LEVELS];
     bool any_split;
     // window mode
     AltGroupsPlan gp;
@@ -817,6 +964,13 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
     pl.ngroups = (pl.Cp + pl.gw - 1) / pl.gw;
     auto pad8 = [](long long n) { return (int)((n + 7) / 8 * 8); };
     pl.seg[0] = window ? B * pad8((long long)pl.qtiles * pl.ngroups) : pad8((long long)B * pl.qtiles * pl.ngroups);
+    // partners per split workgroup: finer where the query tiles alone do not fill the chip twice over and the launch's tail
+    // counts (KITTI: 8 against 12: -1 us on top of the order below; 1080p: 12 against 8: -1 .. 3 % less reduce traffic)
+    int splitf = (long long)B * ptiles * pl.ngroups < 512 ? 8 : 12;
+#if defined(RC_LAB)
+    if (const char* e = getenv("RC_SPLITF")) splitf = atoi(e);
+#endif
+    long long wsteps[RAFTCORR_MAX_LEVELS] = {};              // expected steps of one workgroup of the level, x 256
     size_t pf = 0;
     for (int l = 0; l < L; ++l) {
         const int hl = H >> l, wl = W >> l;
@@ -824,11 +978,26 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
         // query tiles that touch one target tile when the flow is smooth: ((8 + 2r + 2) * 2^l / 8 + 1)^2
         const long long side = (((long long)(8 + 2 * r + 2) << l) >> 3) + 1;
         const long long est = std::min<long long>(ptiles, side * side);
-        pl.nsplit[l] = (int)std::min<long long>(MAXSPLIT, std::max<long long>(1, (est + 11) / 12));
+        pl.nsplit[l] = (int)std::min<long long>(MAXSPLIT, std::max<long long>(1, (est + splitf - 1) / splitf));
         if (l == 0) pl.nsplit[l] = 1;
-        pl.seg[l + 1] = pl.seg[l] + pad8((long long)B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups);
+        // (the estimate above ignores that the map clips the square: deliberately, the levels it overestimates get the
+        // finest splits; for the ORDER the clipped count is the better guess of a workgroup's length)
+        const long long ty_n = (H + QH - 1) / QH, tx_n = (W + QW - 1) / QW;
+        wsteps[l] = 256 * std::min(side, ty_n) * std::min(side, tx_n) / pl.nsplit[l];
         pl.poff[l] = pf;
         if (pl.nsplit[l] > 1) { pf += (size_t)B * pl.ttiles[l] * pl.nsplit[l] * TQ * pl.Cp; pl.any_split = true; }
+    }
+    // Launch order of the d(fmap2) levels: behind the d(fmap1) workgroups (the longest: they walk the boxes of all levels)
+    // level 0, then the split levels by expected workgroup length, the shortest last -- what is dispatched last decides how
+    // long the launch's tail is (KITTI, window groups: 122 -> 114 us per call against the plain order 0 1 2 3).
+    for (int i = 0; i < L; ++i) pl.lorder[i] = i;
+    std::stable_sort(pl.lorder + (L > 1 ? 1 : 0), pl.lorder + L, [&](int a, int b) { return wsteps[a] > wsteps[b]; });
+#if defined(RC_LAB)
+    if (const char* e = getenv("RC_LORDER")) for (int i = 0; i < L && e[i]; ++i) pl.lorder[i] = e[i] - '0';
+#endif
+    for (int i = 0; i < L; ++i) {
+        const int l = pl.lorder[i];
+        pl.seg[i + 1] = pl.seg[i] + pad8((long long)B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups);
     }
     auto up = [](size_t n) { return (n + 255) / 256 * 256; };
     pl.off_boxes = DMAXP * sizeof(float);                    // in front: partial maxima of |dout|
@@ -878,6 +1047,23 @@ int launch_alt_groups(const float* coords, int B, int H, int W, void* groups, si
     w.toff = (int*)((char*)groups + g.off_toff);
     w.cnt = (int*)((char*)groups + g.off_cnt);
     int rc;
+    const int nch64 = (H * W + 63) / 64;
+    bool small = H * W <= WS_MAXQ && ws_small_lds(nch64, g.nb, g.nby) <= 128 * 1024;
+#if defined(RC_LAB)
+    if (getenv("RC_GROUPS_LEGACY")) small = false;
+#endif
+    if (small) {                                             // one launch instead of three
+        static thread_local bool allowed[64] = {};           // > 64 KiB of dynamic LDS: opt in once per device
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess && !allowed[dev & 63]) {
+            e = hipFuncSetAttribute((const void*)alt_wgroups_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e == hipSuccess) allowed[dev & 63] = true;
+        }
+        if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt groups: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(alt_wgroups_small_kernel, dim3(B), dim3(1024), ws_small_lds(nch64, g.nb, g.nby), s, w);
+        return check_launch("alt_wgroups_small_kernel");
+    }
     hipLaunchKernelGGL(alt_wbucket_kernel<false>, dim3(g.nb, g.nch, B), dim3(64), 0, s, w);
     if ((rc = check_launch("alt_wbucket_kernel<count>"))) return rc;
     hipLaunchKernelGGL(alt_wscan_kernel, dim3(B), dim3(1024), 0, s, w);
@@ -939,6 +1125,7 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
         a.poff[l] = (long long)pl.poff[l]; a.nsplit[l] = pl.nsplit[l];
     }
     for (int l = 0; l <= L; ++l) a.seg[l] = pl.seg[l];
+    for (int l = 0; l < L; ++l) a.lorder[l] = pl.lorder[l];
     a.coords = coords; a.dout = dout; a.maxpart = maxpart; a.df1 = df1;
     a.dmax = (const float*)workspace;
     a.boxes = (int4*)((char*)workspace + pl.off_boxes);
@@ -963,12 +1150,12 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
         a.dg = (float*)((char*)workspace + pl.off_dg);
         uint4* f1g = (uint4*)((char*)workspace + pl.off_f1g);
         a.f1t = f1g;
-        hipLaunchKernelGGL(alt_wgather_f1_kernel, dim3(pl.qtiles, pl.Cp / 32, B), dim3(256), 0, s, (const uint4*)f1p_window, f1g,
-                           a.qlist, a.ngr, pl.qtiles, pl.Cp, (size_t)H * W);
-        if ((rc = check_launch("alt_wgather_f1_kernel"))) return rc;
     }
-    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3(B * L * pl.qtiles + DMAXP), dim3(window ? 256 : 64), 0, s, a, B * L * pl.qtiles,
-                       (size_t)B * L * rd2 * H * W);
+    const long long ngather = window ? (long long)B * pl.qtiles * (pl.Cp / 32) : 0;
+    if ((long long)B * L * pl.qtiles + DMAXP + ngather >= ((long long)1 << 31))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
+    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3((unsigned)(B * L * pl.qtiles + DMAXP + ngather)), dim3(window ? 256 : 64), 0, s, a,
+                       B * L * pl.qtiles, (size_t)B * L * rd2 * H * W, (const uint4*)f1p_window);
     rc = check_launch("alt_bwd_pre_kernel");
     if (rc) return rc;
     const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * std::max(rd2, 96) * sizeof(float);

@@ -906,6 +906,58 @@ def test_on_the_fly_backward_takes_the_forward_call_s_groups(dev):
             assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_window_groups_match_a_numpy_model(dev):
+    """The query groups raftcorr_alt_lookup_fwd_sorted leaves in its workspace, read back and compared with a numpy
+    restatement of their definition (csrc/alt_bwd.hip): key = 8x8 level-0 cell of floor(coords) (one ring of cells
+    around the map), the cells of a row laid end to end with their queries in query order, every 64 slots a group, a
+    row's last group padded with -1.  Shapes on both sides of the one-launch / three-launch split of the builder
+    (<= 8192 queries: one workgroup per batch item), map sizes that are no multiples of 8 or 64, coordinates far
+    outside the map and non-finite ones."""
+    from raft_amd import AlternateCorrBlock, _lib
+    lib = _lib.load()
+    for (B, H, W, sigma) in ((1, 47, 156, 3.0), (2, 47, 78, 10.0), (3, 13, 17, 30.0), (1, 40, 240, 4.0), (2, 1, 5, 1.0),
+                             (1, 128, 64, 6.0), (1, 129, 64, 0.0)):
+        D, L, r = 32, 1, 1
+        N = H * W
+        rs = np.random.RandomState(N + B)
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        cn = (np.stack([xx, yy], 0)[None] + sigma * rs.randn(B, 2, H, W)).astype(np.float32)
+        cn.reshape(B, 2, N)[:, :, rs.randint(0, N, size=max(N // 50, 1))] *= -40.0           # far outside
+        cn.reshape(B, 2, N)[0, 0, rs.randint(0, N)] = np.inf
+        cn.reshape(B, 2, N)[B - 1, 1, rs.randint(0, N)] = np.nan
+        cn.reshape(B, 2, N)[0, :, rs.randint(0, N)] = 3.0e6
+        c = _t(cn, dev)
+        f = _t(rs.randn(B, D, H, W).astype(np.float32), dev)
+        blk = AlternateCorrBlock(f, f, num_levels=L, radius=r)
+        gb = lib.raftcorr_alt_lookup_fwd_sorted_workspace_bytes(B, H, W, L)
+        groups = torch.full((gb,), 0x5a, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, L * (2 * r + 1) ** 2, H, W, device=dev)
+        _lib.check(lib.raftcorr_alt_lookup_fwd_sorted(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, L, r,
+                                                      c.data_ptr(), out.data_ptr(), groups.data_ptr(), gb,
+                                                      torch.cuda.current_stream().cuda_stream), "fwd_sorted")
+        raw = groups.cpu().numpy()
+        nbx, nby = (W + 7) // 8 + 2, (H + 7) // 8 + 2
+        gmax = (N + 63) // 64 + nbx * nby
+        ngr = raw[:4 * B].view(np.int32)
+        off = (4 * B + 255) // 256 * 256
+        qlist = raw[off:off + 4 * B * gmax * 64].view(np.int32).reshape(B, gmax * 64)
+
+        def cell(v, n):                                       # csrc/common.h:split_coord + alt_bwd.hip:wbucket_key
+            ok = (v > -1.0e6) & (v < 1.0e6)
+            v0 = np.where(ok, np.floor(np.where(ok, v, 0.0)), -(1 << 24)).astype(np.int64)
+            return np.clip(v0 >> 3, -1, n - 2) + 1
+        for b in range(B):
+            kx, ky = cell(cn[b, 0].reshape(N), nbx), cell(cn[b, 1].reshape(N), nby)
+            want = []
+            for row in range(nby):
+                q = np.nonzero(ky == row)[0]
+                q = q[np.argsort(kx[q], kind="stable")]
+                want.append(np.concatenate([q, -np.ones((-len(q)) % 64, np.int64)]))
+            want = np.concatenate(want)
+            assert ngr[b] == len(want) // 64, (B, H, W, b, ngr[b], len(want) // 64)
+            assert np.array_equal(qlist[b, :len(want)], want), (B, H, W, b)
+
+
 def test_on_the_fly_gradients_sum_in_place(dev):
     """The lookups of one AlternateCorrBlock add their feature gradients into shared sums inside the backward
     kernel (accumulate = 1) instead of handing autograd one dense gradient per lookup.  Same bits as the sum of the
