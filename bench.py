@@ -296,7 +296,7 @@ class KittiAlt(Workload):
                 "products cover whole boxes, i.e. the matrix cores execute several times that")
         tsrc = "r03_pmc_traffic_kitti.json" if load_profile_json("r03_pmc_traffic_kitti.json") else "r02_pmc_traffic_kitti.json"
         tr = load_profile_json(tsrc)
-        k = {"alt_fwd": mfma16_entry("window groups (alt_wbucket x2, alt_wscan) + alt_fwd16_kernel", fwd_us, w["alt_flops"], 3,
+        k = {"alt_fwd": mfma16_entry("window groups (alt_wgroups_small_kernel) + alt_fwd16_kernel", fwd_us, w["alt_flops"], 3,
                                      compulsory_bytes=w["alt_bytes"], hbm_GBs=w["alt_bytes"] / fwd_us / 1e3,
                                      hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, traffic=tr.get("alt_fwd16_kernel"),
                                      traffic_source="profiles/" + tsrc, note=note),
@@ -481,7 +481,7 @@ def extras_kitti(torch, wl, dev):
                                                                              d1.data_ptr(), dlv, 0, swork.data_ptr(), wwork.data_ptr(), wwb,
                                                                              stream))       # groups: what the forward call above left
             hb = dict(compulsory_bytes=w["alt_bytes"])
-            out["alt_fwd_window_tiles_" + tag] = mfma16_entry("alt_wbucket x2 + alt_wscan + alt_fwd16_kernel", ts, w["alt_flops"], 3, **hb)
+            out["alt_fwd_window_tiles_" + tag] = mfma16_entry("window groups (alt_wgroups_small_kernel; alt_wbucket x2 + alt_wscan beyond 8192 queries) + alt_fwd16_kernel", ts, w["alt_flops"], 3, **hb)
             out["alt_fwd_" + tag] = mfma16_entry("alt_fwd16_kernel", tf, w["alt_flops"], 3, hbm_GBs=w["alt_bytes"] / tf / 1e3,
                                                  hbm_frac=w["alt_bytes"] / tf / 1e3 / HBM_PEAK_GBS, **hb)
             hb = dict(compulsory_bytes=w["alt_bwd_bytes"])
@@ -489,11 +489,11 @@ def extras_kitti(torch, wl, dev):
                                                  hbm_GBs=w["alt_bwd_bytes"] / tb / 1e3,
                                                  hbm_frac=w["alt_bwd_bytes"] / tb / 1e3 / HBM_PEAK_GBS, **hb)
             out["alt_bwd_window_groups_" + tag] = mfma16_entry(
-                "alt_wbucket x2 + alt_wscan + alt_wgather_f1 + alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels", tw,
+                "window groups + alt_bwd_pre (windows, d(out) tiles, range pass, fmap1 gather) + alt_bwd + alt_bwd_reduce kernels", tw,
                 w["alt_bwd_flops"], 3, hbm_GBs=w["alt_bwd_bytes"] / tw / 1e3,
                 hbm_frac=w["alt_bwd_bytes"] / tw / 1e3 / HBM_PEAK_GBS, **hb)
             out["alt_bwd_window_groups_of_the_forward_" + tag] = mfma16_entry(
-                "alt_wgather_f1 + alt_bwd_pre + alt_bwd + alt_bwd_reduce kernels (groups from the lookup's forward call)", tg,
+                "alt_bwd_pre (windows, d(out) tiles, range pass, fmap1 gather) + alt_bwd + alt_bwd_reduce kernels (groups from the lookup's forward call)", tg,
                 w["alt_bwd_flops"], 3, hbm_GBs=w["alt_bwd_bytes"] / tg / 1e3,
                 hbm_frac=w["alt_bwd_bytes"] / tg / 1e3 / HBM_PEAK_GBS, **hb)
     # the whole step with 8x8 pixel tiles in the forward pass (the default of AlternateCorrBlock: flow fields are smooth)

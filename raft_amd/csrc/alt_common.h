@@ -112,24 +112,5 @@ __device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile1
     else { t.xmin = mnx; t.ymin = mny; t.bw = mxx - mnx + 1; t.bh = mxy - mny + 1; t.U = t.bw * t.bh; }
 }
 
-template <class Args>
-__device__ __forceinline__ Tile16 tile_setup16(const Args& p, TileQ& sh)
-{
-    Tile16 t;
-    const int tiles_x = (p.W + QW - 1) / QW, tiles = tiles_x * ((p.H + QH - 1) / QH);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int j = idx % p.band, bl = idx / p.band;
-    const int tile = xcd * p.band + j;
-    t.l = bl % p.L;
-    t.b = bl / p.L;
-    t.live = tile < tiles;
-    if (!t.live) return t;                                   // whole workgroup
-    t.ty0 = (tile / tiles_x) * QH;
-    t.tx0 = (tile % tiles_x) * QW;
-    tile_level_setup(p, sh, t);
-    return t;
-}
-
-
 }  // namespace
 }  // namespace raftcorr

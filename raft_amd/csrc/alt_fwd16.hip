@@ -51,6 +51,7 @@ struct AltFwdArgs {
     // list for every level
     const int* qlist;                             // [B][gmax][64] query pixel indices, -1 = empty slot
     const int* ntiles;                            // [B] groups in use
+    int np0;                                      // workgroups per level-0 box (bands of rows), >= 1
     int gmax;
 };
 
@@ -129,24 +130,55 @@ void alt_fwd16_kernel(AltFwdArgs p)
     // would add a memory round trip to every workgroup's critical path)
     const float mp1 = fmaxf(p.maxpart[threadIdx.x & 63], p.maxpart[(threadIdx.x & 63) + 64]);
     const float mp2 = fmaxf(p.maxpart[MAXPARTS16 + (threadIdx.x & 63)], p.maxpart[MAXPARTS16 + (threadIdx.x & 63) + 64]);
+    // Workgroup id -> (XCD band, tile, slot, batch); slot -> (level, part).  A tile's level-0 box is by far its largest (the
+    // window is 2r + 2 wide at every level, the spread of the tile's queries halves with each level), and where the
+    // tiles do not fill the chip the launch lasts as long as its level-0 workgroups.  So level 0 has np0 slots, the
+    // first ones of the launch: a box of three passes and more is cut into np0 bands of rows that share their border
+    // rows, so that the two tap rows of every output element lie in one band and each element has one owner -- no
+    // partial sums to combine.
     Tile16 t;
-    if (p.qlist) {                                           // tiles = query groups; bands as below
+    const int nslots = p.L + p.np0 - 1;
+    int part;
+    {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, j = idx % p.band, bl = idx / p.band;
-        t.l = bl % p.L;
-        t.b = bl / p.L;
-        const int nt = p.ntiles[t.b], bandl = (nt + 7) >> 3, tile = xcd * bandl + j;
-        t.live = j < bandl && tile < nt;
-        if (!t.live) return;                                 // whole workgroup
-        t.ty0 = t.tx0 = 0;
-        tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.gmax + tile) * 64);
-    } else {
-        t = tile_setup16(p, sh);
-        if (!t.live) return;
+        const int slot = bl % nslots;
+        t.l = slot < p.np0 ? 0 : slot - p.np0 + 1;
+        part = slot < p.np0 ? slot : 0;
+        t.b = bl / nslots;
+        if (p.qlist) {                                       // tiles = query groups, bands over the groups in use
+            const int nt = p.ntiles[t.b], bandl = (nt + 7) >> 3, tile = xcd * bandl + j;
+            t.live = j < bandl && tile < nt;
+            if (!t.live) return;                             // whole workgroup
+            t.ty0 = t.tx0 = 0;
+            tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.gmax + tile) * 64);
+        } else {
+            const int tiles_x = (p.W + QW - 1) / QW, tile = xcd * p.band + j;
+            t.live = tile < tiles_x * ((p.H + QH - 1) / QH);
+            if (!t.live) return;                             // whole workgroup
+            t.ty0 = (tile / tiles_x) * QH;
+            t.tx0 = (tile % tiles_x) * QW;
+            tile_level_setup(p, sh, t);
+        }
     }
-    ALT_STAMP();
     const int nkc = p.Cp / KC;
     const size_t P = (size_t)p.H * p.W;
     const int mb = wave & 1, nb0 = wave >> 1;
+    const int qi = tid & 63, g4 = wave;                      // outputs of this thread: query qi, window columns g4 + 4 i
+    float* S = (float*)smem;
+    // rows of first taps this workgroup owns: [own_lo, own_hi)
+    int own_lo = INT_MIN, own_hi = INT_MAX;
+    if (t.l == 0 && p.np0 > 1) {
+        // a box of one or two passes stays whole (smooth flow: the spare workgroups leave here, after the set-up)
+        if (t.U <= 2 * UP || t.bh < 2 * p.np0) { if (part > 0) return; }    // (whole workgroup)
+        else {
+            const int y0 = t.ymin + t.bh * part / p.np0;
+            const int y1 = part + 1 < p.np0 ? t.ymin + t.bh * (part + 1) / p.np0 : t.ymin + t.bh - 1;   // inclusive, shared
+            if (part > 0) own_lo = y0;
+            if (part + 1 < p.np0) own_hi = y1;
+            t.ymin = y0; t.bh = y1 - y0 + 1; t.U = t.bw * t.bh;
+        }
+    }
+    ALT_STAMP();
 
     const uint4* __restrict__ f1b = p.f1p + (size_t)t.b * P * nkc * 8;
     const uint4* __restrict__ f2b = p.f2p[t.l] + (size_t)t.b * t.HWl * nkc * 8;
@@ -159,14 +191,11 @@ void alt_fwd16_kernel(AltFwdArgs p)
     }
 
     // outputs of this thread: query qi = tid & 63, window columns a = g4 + 4 i (g4 = wave: uniform per wave)
-    const int qi = tid & 63, g4 = wave;
     float o[NCOL][RDM];
 #pragma unroll
     for (int i = 0; i < NCOL; ++i)
 #pragma unroll
         for (int bb = 0; bb < RDM; ++bb) o[i][bb] = 0.f;
-
-    float* S = (float*)smem;
 
     for (int ubase = 0; ubase < t.U; ubase += UP) {
         __syncthreads();                                     // previous pass: S and toff are no longer read
@@ -295,7 +324,7 @@ void alt_fwd16_kernel(AltFwdArgs p)
     if (threadIdx.x == 0) { stamps[14] = (unsigned long long)t.l; stamps[15] = (unsigned long long)t.U; }
     return;
 #endif
-    const int myqi = sh.qpix[qi];
+    const int myqi = sh.qpix[qi], wy0q = sh.wy0[qi];
     const float unscale = ldexpf(1.0f, -(range_exp16(wave_max128(mp1)) + range_exp16(wave_max128(mp2))));
     if (myqi >= 0) {
         float* __restrict__ out = p.out + (((size_t)t.b * p.L + t.l) * rd2) * P + myqi;
@@ -304,8 +333,10 @@ void alt_fwd16_kernel(AltFwdArgs p)
             const int a = g4 + 4 * i;
             if (a < rd) {
 #pragma unroll
-                for (int bb = 0; bb < RDM; ++bb)
-                    if (bb < rd) out[(size_t)(a * rd + bb) * P] = (o[i][bb] * unscale) / p.sqrt_c;
+                for (int bb = 0; bb < RDM; ++bb) {
+                    const int r0 = wy0q + bb;                // row of the element's first tap
+                    if (bb < rd && r0 >= own_lo && r0 < own_hi) out[(size_t)(a * rd + bb) * P] = (o[i][bb] * unscale) / p.sqrt_c;
+                }
             }
         }
     }
@@ -367,7 +398,16 @@ int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float
         a.band = (gp.gmax + 7) / 8;
     }
     const size_t sm = std::max((size_t)2 * STG * sizeof(uint4), (size_t)TQ * LDS_S * sizeof(float));
-    const dim3 grid(8u * a.band * L * B);
+    // Level-0 boxes of three passes and more in two bands of rows (see the kernel) where the tiles do not fill the chip.
+    // KITTI, per call: window groups under random walks 51 -> 46 us, pixel tiles 57 / 83 / 102 -> 42 / 50 / 61 us at
+    // sigma = 3 / 4.2 / 6; smooth flow (boxes of two passes, nothing is cut) pays the set-up of the spare workgroups.
+    // 1080p (2080 workgroups before the cut): 185 -> 205 us, left whole.
+    const long long ntile = workspace ? ((long long)H * W + TQ - 1) / TQ : tiles;
+    a.np0 = (long long)B * ntile * L < 1024 ? 2 : 1;
+#if defined(RC_LAB)
+    if (const char* e = getenv("RC_NP0")) a.np0 = atoi(e) >= 1 ? atoi(e) : 1;
+#endif
+    const dim3 grid(8u * a.band * (L + a.np0 - 1) * B);
     static thread_local bool allowed[64][2] = {};            // >64 KiB of dynamic LDS: opt in once per device and kernel
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

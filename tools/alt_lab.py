@@ -41,6 +41,6 @@ if "STAMPS" in _lib.LIB_PATH:
             m = stp[stp[:, 14] == l]
             if len(m) == 0: continue
             rel = (m[:, :14] - t0) / 100.0
-            npass = ((m[:, 15] + 255) // 256)
+            npass = np.minimum((m[:, 15] + 191) // 192, 3)
             # stamps: 0 start, 1 setup, then per pass: K start, K end, S written; last: end
             print(f" level {l}: U avg {m[:,15].mean():.0f} passes {npass.mean():.1f} | start {rel[:,0].mean():.2f} setup {rel[:,1].mean():.2f} | pass0: Kstart {rel[:,2].mean():.2f} Kend {rel[:,3].mean():.2f} Swritten {rel[:,4].mean():.2f} | last stamp avg {np.array([rel[i, 2 + 3 * npass[i]] for i in range(len(m))]).mean():.2f} max {np.array([rel[i, 2 + 3 * npass[i]] for i in range(len(m))]).max():.2f}")
