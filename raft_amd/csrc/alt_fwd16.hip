@@ -51,7 +51,7 @@ struct AltFwdArgs {
     // list for every level
     const int* qlist;                             // [B][gmax][64] query pixel indices, -1 = empty slot
     const int* ntiles;                            // [B] groups in use
-    int np0;                                      // workgroups per level-0 box (bands of rows), >= 1
+    int np0, np1;                                 // workgroups per level-0 / level-1 box (bands of rows), >= 1 (np1 = 1 when L = 1)
     int gmax;
 };
 
@@ -137,13 +137,14 @@ void alt_fwd16_kernel(AltFwdArgs p)
     // rows, so that the two tap rows of every output element lie in one band and each element has one owner -- no
     // partial sums to combine.
     Tile16 t;
-    const int nslots = p.L + p.np0 - 1;
-    int part;
+    const int nslots = p.L + p.np0 - 1 + p.np1 - 1;
+    int part, np;
     {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, j = idx % p.band, bl = idx / p.band;
         const int slot = bl % nslots;
-        t.l = slot < p.np0 ? 0 : slot - p.np0 + 1;
-        part = slot < p.np0 ? slot : 0;
+        if (slot < p.np0)              { t.l = 0; part = slot; np = p.np0; }
+        else if (slot < p.np0 + p.np1) { t.l = 1; part = slot - p.np0; np = p.np1; }
+        else                           { t.l = slot - p.np0 - p.np1 + 2; part = 0; np = 1; }
         t.b = bl / nslots;
         if (p.qlist) {                                       // tiles = query groups, bands over the groups in use
             const int nt = p.ntiles[t.b], bandl = (nt + 7) >> 3, tile = xcd * bandl + j;
@@ -167,14 +168,14 @@ void alt_fwd16_kernel(AltFwdArgs p)
     float* S = (float*)smem;
     // rows of first taps this workgroup owns: [own_lo, own_hi)
     int own_lo = INT_MIN, own_hi = INT_MAX;
-    if (t.l == 0 && p.np0 > 1) {
+    if (np > 1) {
         // a box of one or two passes stays whole (smooth flow: the spare workgroups leave here, after the set-up)
-        if (t.U <= 2 * UP || t.bh < 2 * p.np0) { if (part > 0) return; }    // (whole workgroup)
+        if (t.U <= 2 * UP || t.bh < 2 * np) { if (part > 0) return; }    // (whole workgroup)
         else {
-            const int y0 = t.ymin + t.bh * part / p.np0;
-            const int y1 = part + 1 < p.np0 ? t.ymin + t.bh * (part + 1) / p.np0 : t.ymin + t.bh - 1;   // inclusive, shared
+            const int y0 = t.ymin + t.bh * part / np;
+            const int y1 = part + 1 < np ? t.ymin + t.bh * (part + 1) / np : t.ymin + t.bh - 1;   // inclusive, shared
             if (part > 0) own_lo = y0;
-            if (part + 1 < p.np0) own_hi = y1;
+            if (part + 1 < np) own_hi = y1;
             t.ymin = y0; t.bh = y1 - y0 + 1; t.U = t.bw * t.bh;
         }
     }
@@ -404,10 +405,12 @@ int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float
     // 1080p (2080 workgroups before the cut): 185 -> 205 us, left whole.
     const long long ntile = workspace ? ((long long)H * W + TQ - 1) / TQ : tiles;
     a.np0 = (long long)B * ntile * L < 1024 ? 2 : 1;
+    a.np1 = 1;
 #if defined(RC_LAB)
     if (const char* e = getenv("RC_NP0")) a.np0 = atoi(e) >= 1 ? atoi(e) : 1;
+    if (const char* e = getenv("RC_NP1")) a.np1 = atoi(e) >= 1 && L > 1 ? atoi(e) : 1;
 #endif
-    const dim3 grid(8u * a.band * (L + a.np0 - 1) * B);
+    const dim3 grid(8u * a.band * (L + a.np0 - 1 + a.np1 - 1) * B);
     static thread_local bool allowed[64][2] = {};            // >64 KiB of dynamic LDS: opt in once per device and kernel
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
