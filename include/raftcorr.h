@@ -321,6 +321,30 @@ int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles
                                    float* dfmap1, float* const* dfmap2_levels, int accumulate,
                                    const void* groups, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Deferred form of the two backward calls above for the training path, where ONE frame pair is looked up K times
+ * (core/raft.py:123-125) before autograd reaches the features: a lookup's backward pass only keeps its (coords, d(out),
+ * groups), and this call does the work of n_lookups calls at once -- the kernels run over n_lookups x B "virtual" batch
+ * items, which fills the chip where one lookup of one pair does not (KITTI size: 77 instead of 116 us per lookup).
+ *   coords, douts    HOST arrays of n_lookups DEVICE pointers, as the single calls take them ((B,2,H,W), (B,L*rd*rd,H,W))
+ *   window           0: pixel tiles, fmap1_packed = the tile-major copy (raftcorr_alt_pack_tiles), groups ignored;
+ *                    1: window groups, fmap1_packed = the forward pass' copy (raftcorr_alt_pack), groups = HOST array of
+ *                       n_lookups DEVICE pointers (the workspaces of raftcorr_alt_lookup_fwd_sorted for the same coords;
+ *                       an entry or the whole array may be NULL: those groups are built here)
+ *   dfmap1, dfmap2_levels   receive (accumulate != 0: are added to) the SUM over the lookups, added in array order: the
+ *                    same float additions in the same order as n_lookups single calls with accumulate = 1, i.e. the
+ *                    same bits; no atomics, bit-reproducible
+ *   workspace        raftcorr_alt_lookup_bwd_many_workspace_bytes(...) bytes, 256-byte aligned, contents don't-care (it
+ *                    holds every lookup's tables, d(out) tiles and gradients: ~80 MB per lookup at KITTI size)
+ * n_lookups <= RAFTCORR_ALT_MAX_LOOKUPS per call; longer lists are cut by the caller (accumulate = 1 from the second). */
+#define RAFTCORR_ALT_MAX_LOOKUPS 16
+int64_t raftcorr_alt_lookup_bwd_many_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius, int n_lookups,
+                                                     int window);
+int raftcorr_alt_lookup_bwd_many(const void* fmap1_packed, const void* const* tiles2_levels, const float* scales,
+                                 int B, int H, int W, int C, int num_levels, int radius, int n_lookups,
+                                 const float* const* coords, const float* const* douts, const void* const* groups, int window,
+                                 float* dfmap1, float* const* dfmap2_levels, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Set-up and tear-down of one frame pair of the on-the-fly block, one host call each (what core/corr.py:64-73 does in
  * its constructor -- the avg_pool2d chain -- plus the packed copies the kernels above read; and its adjoint).
  *   raftcorr_alt_prepare       = raftcorr_alt_scales + the fmap2 pyramid (avg_pool2d(., 2, stride=2) chain, levels

@@ -77,6 +77,10 @@ _SIGNATURES = {
     "raftcorr_alt_lookup_bwd_sorted": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 6 +
                                        [_c_fp, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_fp, _c_fp, ctypes.c_int64,
                                         ctypes.c_void_p], _c_int),
+    "raftcorr_alt_lookup_bwd_many_workspace_bytes": ([_c_int] * 8, ctypes.c_int64),
+    "raftcorr_alt_lookup_bwd_many": ([_c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp] + [_c_int] * 7 +
+                                     [ctypes.POINTER(ctypes.c_void_p)] * 3 + [_c_int, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_int,
+                                      _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_prepare_workspace_bytes": ([_c_int] * 5, ctypes.c_int64),
     "raftcorr_alt_prepare": ([_c_fp, _c_fp] + [_c_int] * 5 + [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_void_p), _c_fp,
                                                               ctypes.POINTER(ctypes.c_void_p), _c_fp, ctypes.c_int64,
@@ -148,6 +152,9 @@ def check(rc, what):
     if rc != 0:
         msg = load().raftcorr_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"raftcorr {what} failed (code {rc}): {msg}")
+
+
+ALT_MAX_LOOKUPS = 16                                   # RAFTCORR_ALT_MAX_LOOKUPS (include/raftcorr.h)
 
 
 def ptr_array(tensors):

@@ -29,6 +29,8 @@ fallback path: without the HIP extension every operator raises RuntimeError.
 import contextlib
 import ctypes
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
@@ -623,6 +625,21 @@ class _AltGradState:
     def __init__(self, shape, num_levels, device):
         self.shape, self.L, self.device = shape, num_levels, device
         self.acc = self.ptrs = self.task = None
+        self.records, self.rtask = [], None                     # deferred backward: (coords, d(out), groups) per lookup
+
+    def record(self, coords, dout, groups):
+        """Deferred backward pass: keep what a lookup's backward call was given; _AltFeatures.backward, which runs after
+        all of them, does the work in one library call.  Records of an earlier pass that never reached the features are
+        dropped."""
+        task = _graph_task_id()
+        if self.rtask != task:
+            self.records, self.rtask = [], task
+        self.records.append((coords, dout, groups))
+
+    def take_records(self):
+        rec = self.records if self.rtask == _graph_task_id() else []
+        self.records, self.rtask = [], None
+        return rec
 
     def buffers(self):
         """(sums, first) for the backward pass that is running now; `first`: nothing of this pass is in them yet (the
@@ -644,6 +661,31 @@ class _AltGradState:
         return acc
 
 
+def _alt_backward_many(st, rec):
+    """raftcorr_alt_lookup_bwd_many over the recorded lookups (in the order their backward calls arrived), at most
+    ALT_MAX_LOOKUPS per call; sums into the state's buffers like the per-lookup calls do."""
+    lib = _lib.load()
+    blk = st.blk()
+    if blk is None:
+        raise RuntimeError("AlternateCorrBlock: the block was released before its backward pass ran")
+    B, C, H, W = st.shape
+    L, window = st.L, blk.tiles == "window"
+    f1 = blk._p1 if window else blk._t1
+    for i in range(0, len(rec), _lib.ALT_MAX_LOOKUPS):
+        part = rec[i:i + _lib.ALT_MAX_LOOKUPS]
+        acc, first = st.buffers()
+        n = len(part)
+        nbytes = lib.raftcorr_alt_lookup_bwd_many_workspace_bytes(B, H, W, C, L, blk.radius, n, 1 if window else 0)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=st.device)
+        coords, douts = [p[0] for p in part], [p[1] for p in part]
+        with _guard(coords[0]):
+            _lib.check(lib.raftcorr_alt_lookup_bwd_many(f1.data_ptr(), blk._t2ptrs, blk._scales.data_ptr(), B, H, W, C, L,
+                                                        blk.radius, n, _lib.ptr_array(coords), _lib.ptr_array(douts),
+                                                        _lib.ptr_array([p[2] for p in part]) if window else None,
+                                                        1 if window else 0, acc[0].data_ptr(), st.ptrs, 0 if first else 1,
+                                                        work.data_ptr(), nbytes, _stream(coords[0])), "alt_lookup_bwd_many")
+
+
 class _AltFeatures(torch.autograd.Function):
     """fmap1, fmap2 -> anchor.  Like _BuildPyramid's anchor: a 1-element tensor that every lookup of the block takes
     as an input.  The lookups' backward passes add their feature gradients into the block's sums in place
@@ -661,6 +703,9 @@ class _AltFeatures(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, danchor):
         st = ctx.state
+        rec = st.take_records()
+        if rec:                                                 # deferred: all lookups of the pass in one library call
+            _alt_backward_many(st, rec)
         acc = st.take()
         if acc is None:                                         # no lookup of this backward pass reached the features
             return None, None, None
@@ -695,6 +740,10 @@ class _AltLookup(torch.autograd.Function):
         B, C, H, W = blk._shape
         L = blk.num_levels
         dout = _f32c(dout)
+        if blk.backward == "deferred":                          # the work is done once, by the features' node
+            blk._gstate.record(coords, dout, ctx.groups)
+            ctx.groups = None
+            return None, None, None
         acc, first = blk._gstate.buffers()
         work = blk._bwd_workspace()
         with _guard(coords):
@@ -729,15 +778,24 @@ class AlternateCorrBlock:
     right choice for flow fields (neighbours look at neighbouring windows).  "window": queries are dealt into tiles by
     the position of their windows in a small extra launch per call (raftcorr_alt_lookup_fwd_sorted) -- the cost no
     longer depends on how coherent the flow is (per-pixel random offsets of a few pixels cost pixel tiles 2-4x);
-    about 10 us per call more when the flow is smooth.  Same results up to the last bit of a sum -- also from run to
-    run: tile membership follows the order of the bucket kernel's atomics (pixel tiles are bit-reproducible)."""
+    about 10 us per call more when the flow is smooth.  Same results up to the last bit of a sum; the groups are a
+    function of the coordinates alone, so both modes are bit-reproducible from run to run.
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, tiles="pixel"):
+    backward: "deferred" (default): a lookup's backward call only keeps its (coords, d(out), groups); the node of the
+    features, which autograd runs after all lookups of the pass, computes the feature gradients of all of them in one
+    library call (raftcorr_alt_lookup_bwd_many: the kernels run over lookups x batch items at once, which fills the
+    chip where one lookup of one frame pair does not).  "per_lookup": every lookup's backward call runs the kernels
+    itself and adds into the block's sums in place.  Same bits either way (the same additions in the same order)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, tiles="pixel", backward="deferred"):
         self.num_levels = num_levels
         self.radius = radius
         if tiles not in ("pixel", "window"):
             raise RuntimeError("AlternateCorrBlock: tiles must be 'pixel' or 'window'")
+        if backward not in ("deferred", "per_lookup"):
+            raise RuntimeError("AlternateCorrBlock: backward must be 'deferred' or 'per_lookup'")
         self.tiles = tiles
+        self.backward = backward
         self._sort_work = None
         _require_cuda(fmap1=fmap1, fmap2=fmap2)
         if fmap1.dim() != 4 or fmap1.shape != fmap2.shape:
@@ -788,6 +846,7 @@ class AlternateCorrBlock:
                                                 work.data_ptr(), work.numel(), _stream(f1)), "alt_prepare")
         if self._grad:
             self._gstate = _AltGradState(self._shape, num_levels, dev)
+            self._gstate.blk = weakref.ref(self)
             self._anchor = _AltFeatures.apply(self._gstate, fmap1, fmap2)
         self._work = None                                       # workspace of the backward kernels, shared by the lookups
 

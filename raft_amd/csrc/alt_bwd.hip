@@ -42,15 +42,20 @@ constexpr int IMG_A = TQ * 16;                    // uint4 slots of the G image 
 constexpr int IMG_B = CG * 16;                    // uint4 slots of the partner image [CG channel rows][16 slots]
 constexpr int MAXSPLIT = 32;
 constexpr int DMAXP = 512;                        // partial maxima of |d(out)| (alt_bwd_pre_kernel)
+constexpr int ALT_KMAX = 16;                      // lookups per call (kernel-argument arrays)
 
 struct AltBwdArgs {
     const uint4* f1t;                             // tile-major fmap1: [B][qtiles][Cp][16 slots]
     const uint4* f2t[RAFTCORR_MAX_LEVELS];        // tile-major pooled fmap2, level l: [B][ttiles_l][Cp][16]
     int hl[RAFTCORR_MAX_LEVELS], wl[RAFTCORR_MAX_LEVELS];
-    const float* coords;                          // (B, 2, H, W)
-    const float* dout;                            // (B, L*rd*rd, H, W)
+    // One call serves nk lookups of the same frame pair(s) at once (the deferred backward pass): the kernels run over a
+    // VIRTUAL batch B = nk * Bf, item b = lookup b / Bf of real batch item b % Bf.  Per-lookup inputs come as arrays,
+    // the features are indexed by the real item, everything in the workspace and the outputs by the virtual one.
+    const float* coords_k[ALT_KMAX];              // per lookup: (Bf, 2, H, W)
+    const float* dout_k[ALT_KMAX];                // per lookup: (Bf, L*rd*rd, H, W)
+    int nk, Bf;
     const float* maxpart;                         // [2][128] partial maxima of |fmap1|, |fmap2| (pack scales)
-    const float* dmax;                            // [DMAXP] partial maxima of |dout|
+    const float* dmax;                            // [nk][DMAXP] partial maxima of |dout| per lookup
     float* df1;                                   // (B, H, W, C)
     float* df2[RAFTCORR_MAX_LEVELS];              // (B, H_l, W_l, C)
     int4* boxes;                                  // [B][L][qtiles]: (xmin, xmax, ymin, ymax) of the tile's windows at level l
@@ -70,8 +75,9 @@ struct AltBwdArgs {
     // 8x8 cell (alt_wfill_kernel: groups in bucket order, members in query order -- a function of the coordinates
     // alone); qtiles = group slots per batch item, ngr[b] of them in use.  f1t then is the tile-major copy of fmap1
     // gathered for the groups, dg the groups' d(out) tiles [B][L][qtiles][rd*rd][64].
-    const int* qlist;                             // [B][qtiles][64] query pixel indices, -1 = empty slot
-    const int* ngr;                               // [B]
+    bool window;
+    const int* qlist_k[ALT_KMAX];                 // per lookup: [Bf][qtiles][64] query pixel indices, -1 = empty slot
+    const int* ngr_k[ALT_KMAX];                   // per lookup: [Bf]
     float* dg;
 };
 
@@ -83,12 +89,34 @@ struct BwdSh {
 };
 
 // exponent that maps max|d(out)| into [2^14, 2^15): every wave reduces the DMAXP partial maxima itself
-__device__ __forceinline__ int dout_exp(const AltBwdArgs& p, int lane)
+__device__ __forceinline__ int dout_exp(const AltBwdArgs& p, int lane, int look)
 {
     float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < DMAXP / 64; ++i) m = fmaxf(m, p.dmax[lane + 64 * i]);
+    for (int i = 0; i < DMAXP / 64; ++i) m = fmaxf(m, p.dmax[look * DMAXP + lane + 64 * i]);
     return range_exp16(wave_max128(m));
+}
+
+// virtual batch item b -> its lookup's inputs
+__device__ __forceinline__ const float* coords_of(const AltBwdArgs& p, int b)
+{
+    const int look = b / p.Bf;
+    return p.coords_k[look] + (size_t)(b - look * p.Bf) * 2 * p.H * p.W;
+}
+__device__ __forceinline__ const float* dout_of(const AltBwdArgs& p, int b)       // (L*rd*rd, H, W) of the item
+{
+    const int look = b / p.Bf, rd = 2 * p.r + 1;
+    return p.dout_k[look] + (size_t)(b - look * p.Bf) * p.L * rd * rd * p.H * p.W;
+}
+__device__ __forceinline__ const int* qlist_of(const AltBwdArgs& p, int b)        // [qtiles][64] of the item
+{
+    const int look = b / p.Bf;
+    return p.qlist_k[look] + (size_t)(b - look * p.Bf) * p.qtiles * TQ;
+}
+__device__ __forceinline__ int ngr_of(const AltBwdArgs& p, int b)
+{
+    const int look = b / p.Bf;
+    return p.ngr_k[look][b - look * p.Bf];
 }
 
 __device__ __forceinline__ int ttx_of(const AltBwdArgs& p, int l) { return (p.wl[l] + 7) >> 3; }
@@ -364,17 +392,15 @@ void alt_wgroups_small_kernel(WSortArgs p)
 // tile-major copy of fmap1 for the groups (the partner images of the d(fmap2) role), gathered from the forward
 // pass' packed copy [pixel][Cp/32][hi: 4 slots of 8 channels | lo: 4 slots] (alt_fwd16.hip; same scaling).
 // One workgroup of 256 threads per (group g, 32-channel chunk, batch item); lines: TQ * 8 slots of LDS
-__device__ __forceinline__ void wgather_f1(const uint4* __restrict__ f1p, uint4* __restrict__ f1g, const int* __restrict__ qlist,
-                                           const int* __restrict__ ngr, int qtiles, int Cp, size_t P, int g, int chunk, int b,
-                                           uint4* lines)
+// f1p: the packed map of the REAL batch item; ql: the group's 64 query indices; f1g: the group's image (Cp rows)
+__device__ __forceinline__ void wgather_f1(const uint4* __restrict__ f1p, uint4* __restrict__ f1g, const int* __restrict__ ql,
+                                           int Cp, int chunk, uint4* lines)
 {
     const int tid = threadIdx.x, nkc = Cp / 32;
-    if (g >= ngr[b]) return;
-    const int* __restrict__ ql = qlist + ((size_t)b * qtiles + g) * TQ;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = tid + 256 * i, pix = ql[e >> 3];
-        const uint4 v = f1p[(((size_t)b * P + max(pix, 0)) * nkc + chunk) * 8 + (e & 7)];
+        const uint4 v = f1p[((size_t)max(pix, 0) * nkc + chunk) * 8 + (e & 7)];
         lines[e] = pix >= 0 ? v : make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
@@ -388,7 +414,7 @@ __device__ __forceinline__ void wgather_f1(const uint4* __restrict__ f1p, uint4*
         uint4 w;
         w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
         w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
-        f1g[(((size_t)b * qtiles + g) * Cp + chunk * 32 + c) * 16 + sl] = w;
+        f1g[(size_t)(chunk * 32 + c) * 16 + sl] = w;
     }
 }
 
@@ -396,7 +422,7 @@ __device__ __forceinline__ void wgather_f1(const uint4* __restrict__ f1p, uint4*
 // The small passes in front of the main kernel, in one launch (they do not depend on each other):
 //   workgroups [0, nwin = B * L * qtiles): per (batch, level, query tile) the 64 windows (origin + fractions), their
 //                        bounding box and, in window mode, the group's d(out) tile;
-//   the DMAXP workgroups after them: partial maxima of |d(out)| (n floats), the range of the G images;
+//   the nk * DMAXP workgroups after them: partial maxima of |d(out)| per lookup (n floats each), the range of the G images;
 //   window mode, ngather more: the groups' tile-major copy of fmap1 (wgather_f1), one workgroup per (group, 32-channel
 //                        chunk, batch item).
 // block 64 (pixel tiles) or 256 (window mode)
@@ -406,15 +432,18 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n, const uint4* __restric
     __shared__ TileQ sh;
     __shared__ uint4 lines[TQ * 8];               // wgather_f1: the queries' 128-byte lines of one channel chunk
     __shared__ float red[4];
-    if ((int)blockIdx.x >= nwin + DMAXP) {
-        const int idx = blockIdx.x - nwin - DMAXP, nkc = p.Cp / 32;
-        wgather_f1(f1p, const_cast<uint4*>(p.f1t), p.qlist, p.ngr, p.qtiles, p.Cp, (size_t)p.H * p.W,
-                   idx % p.qtiles, (idx / p.qtiles) % nkc, idx / (p.qtiles * nkc), lines);
+    if ((int)blockIdx.x >= nwin + p.nk * DMAXP) {
+        const int idx = blockIdx.x - nwin - p.nk * DMAXP, nkc = p.Cp / 32;
+        const int g = idx % p.qtiles, chunk = (idx / p.qtiles) % nkc, b = idx / (p.qtiles * nkc);
+        if (g >= ngr_of(p, b)) return;                       // (whole workgroup)
+        wgather_f1(f1p + (size_t)(b % p.Bf) * p.H * p.W * nkc * 8, const_cast<uint4*>(p.f1t) + ((size_t)b * p.qtiles + g) * p.Cp * 16,
+                   qlist_of(p, b) + (size_t)g * TQ, p.Cp, chunk, lines);
         return;
     }
     if ((int)blockIdx.x >= nwin) {
-        const int j = blockIdx.x - nwin, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        const float* __restrict__ x = p.dout;
+        const int j = (blockIdx.x - nwin) % DMAXP, look = (blockIdx.x - nwin) / DMAXP;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const float* __restrict__ x = p.dout_k[look];
         float m = 0.f;
         const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;       // 16-byte loads when aligned
         const size_t STRIDE = (size_t)DMAXP * nw * 64;
@@ -438,7 +467,7 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n, const uint4* __restric
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int u = 1; u < nw; ++u) m = fmaxf(m, red[u]);
-            const_cast<float*>(p.dmax)[j] = m;
+            const_cast<float*>(p.dmax)[look * DMAXP + j] = m;
         }
         return;
     }
@@ -446,18 +475,18 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n, const uint4* __restric
     const int q = threadIdx.x;
     Tile16 t;
     t.l = bl % p.L; t.b = bl / p.L;
-    if (p.qlist) {                                           // window mode: the tile is a group of the list
-        if (tile >= p.ngr[t.b]) {                            // slot not in use: an empty box keeps it out of every walk
+    if (p.window) {                                          // window mode: the tile is a group of the list
+        if (tile >= ngr_of(p, t.b)) {                        // slot not in use: an empty box keeps it out of every walk
             if (q == 0) p.boxes[blockIdx.x] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
             return;
         }
         t.ty0 = t.tx0 = 0;
-        tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.qtiles + tile) * TQ);
+        tile_level_setup(p, sh, t, coords_of(p, t.b), qlist_of(p, t.b) + (size_t)tile * TQ);
         // the group's d(out) tile [rd*rd][64], gathered once: the main kernel then fetches it with contiguous loads.
         // Four waves, each every fourth batch of 16 channels.
         const int rd2 = (2 * p.r + 1) * (2 * p.r + 1), qq = q & 63, pix = sh.qpix[qq];
         const size_t P = (size_t)p.H * p.W;
-        const float* __restrict__ src = p.dout + ((size_t)t.b * p.L + t.l) * rd2 * P + max(pix, 0);
+        const float* __restrict__ src = dout_of(p, t.b) + (size_t)t.l * rd2 * P + max(pix, 0);
         float* __restrict__ dst = p.dg + (size_t)blockIdx.x * rd2 * TQ + qq;
         for (int c0 = 16 * (q >> 6); c0 < rd2; c0 += 16 * (blockDim.x >> 6)) {     // 16 loads in flight
             float v[16];
@@ -470,7 +499,7 @@ void alt_bwd_pre_kernel(AltBwdArgs p, int nwin, size_t n, const uint4* __restric
         if (q >= 64) return;
     } else {
         t.ty0 = (tile / p.qtx) * QH; t.tx0 = (tile % p.qtx) * QW;
-        tile_level_setup(p, sh, t);
+        tile_level_setup(p, sh, t, coords_of(p, t.b));
     }
     p.wins[(size_t)blockIdx.x * TQ + q] = make_int4(sh.wx0[q], sh.wy0[q], __float_as_int(sh.fx[q]), __float_as_int(sh.fy[q]));
     if (q == 0) p.boxes[blockIdx.x] = make_int4(sh.box[0], sh.box[1], sh.box[2], sh.box[3]);
@@ -522,7 +551,7 @@ struct DTile {
 __device__ __forceinline__ const float* dtile_source(const AltBwdArgs& p, int b, int l, int qt, int rd2, int q,
                                                      size_t& stride, unsigned& lane_off)
 {
-    if (p.qlist) {
+    if (p.window) {
         stride = TQ; lane_off = (unsigned)q;
         return p.dg + (((size_t)b * p.L + l) * p.qtiles + qt) * rd2 * TQ;
     }
@@ -530,7 +559,7 @@ __device__ __forceinline__ const float* dtile_source(const AltBwdArgs& p, int b,
     const int gy = (qt / p.qtx) * QH + (q >> 3), gx = (qt % p.qtx) * QW + (q & 7);
     stride = P;
     lane_off = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) : 0u;               // out-of-map queries: any address
-    return p.dout + ((size_t)b * p.L + l) * rd2 * P;
+    return dout_of(p, b) + (size_t)l * rd2 * P;
 }
 
 __device__ __forceinline__ void dtile_issue(const AltBwdArgs& p, DTile& d, int b, int l, int qt, int rd2, int wave)
@@ -716,10 +745,8 @@ void alt_bwd_kernel(AltBwdArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mb = wave & 1, nb0 = wave >> 1;
     const int rd = 2 * p.r + 1, rd2 = rd * rd;
-    const int eg = dout_exp(p, lane);
     const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
     const int e2 = range_exp16(wave_max128(fmaxf(p.maxpart[MAXPARTS16 + lane], p.maxpart[MAXPARTS16 + lane + 64])));
-    const float sg = ldexpf(1.0f, eg);
     const size_t P = (size_t)p.H * p.W;
     const int wg = blockIdx.x;
 
@@ -739,12 +766,12 @@ void alt_bwd_kernel(AltBwdArgs p)
     if (wg < p.seg[0]) {
         // ---------------- d(fmap1): owner = query tile, partners = target tiles of every level ----------------
         int g, tile, b;
-        if (p.qlist) {
+        if (p.window) {
             // window mode: the segment holds pad8(qtiles * ngroups) ids per batch item, but only ngr[b] group slots are
             // in use: the bands are eighths of THOSE (groups are in bucket order = bands of image rows)
             const int perb = (p.qtiles * p.ngroups + 7) & ~7;
             b = wg / perb;
-            const int wb = wg - b * perb, n_items = p.ngr[b] * p.ngroups, band = (n_items + 7) >> 3;
+            const int wb = wg - b * perb, n_items = ngr_of(p, b) * p.ngroups, band = (n_items + 7) >> 3;
             const int item = (wb & 7) * band + (wb >> 3);
             if ((wb >> 3) >= band || item >= n_items) return;    // (whole workgroup)
             g = item % p.ngroups; tile = item / p.ngroups;
@@ -756,6 +783,9 @@ void alt_bwd_kernel(AltBwdArgs p)
             tile = rest % p.qtiles; b = rest / p.qtiles;
         }
         const int rows = min(p.gw, p.Cp - g * p.gw);             // channels of this workgroup (a multiple of 32)
+        const int fb = b % p.Bf;                                 // the real batch item behind the virtual one
+        const int eg = dout_exp(p, lane, b / p.Bf);
+        const float sg = ldexpf(1.0f, eg);
         DTile dt;
         dtile_issue(p, dt, b, 0, tile, rd2, wave);
         for (int l = 0; l < p.L; ++l) {
@@ -766,7 +796,7 @@ void alt_bwd_kernel(AltBwdArgs p)
             __syncthreads();
             if (box.x > box.y || box.z > box.w) continue;
             const int ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
-            const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)b * ttiles * p.Cp + g * p.gw) * 16;
+            const uint4* __restrict__ f2b = p.f2t[l] + ((size_t)fb * ttiles * p.Cp + g * p.gw) * 16;
             for (int ty = box.z >> 3; ty <= box.w >> 3; ++ty)
                 for (int tx = box.x >> 3; tx <= box.y >> 3; ++tx) {
                     pair_step<false>(f2b + (size_t)(ty * ttx + tx) * p.Cp * 16, rows, Bimg, Aimg, D, sh, ty * 8, tx * 8, rd, sg,
@@ -780,7 +810,7 @@ void alt_bwd_kernel(AltBwdArgs p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-            if (p.qlist) opix[i] = p.qlist[((size_t)b * p.qtiles + tile) * TQ + q];
+            if (p.window) opix[i] = qlist_of(p, b)[(size_t)tile * TQ + q];
             else {
                 const int gy = (tile / p.qtx) * QH + (q >> 3), gx = (tile % p.qtx) * QW + (q & 7);
                 opix[i] = (gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
@@ -820,8 +850,11 @@ void alt_bwd_kernel(AltBwdArgs p)
     const int b = idx;
     const int rows = min(p.gw, p.Cp - g * p.gw);                 // channels of this workgroup (a multiple of 32)
     const int ty0 = (tt / ttx) * 8, tx0 = (tt % ttx) * 8;
+    const int eg = dout_exp(p, lane, b / p.Bf);
+    const float sg = ldexpf(1.0f, eg);
     const int4* __restrict__ boxes = p.boxes + ((size_t)b * p.L + l) * p.qtiles;
-    const uint4* __restrict__ f1b = p.f1t + ((size_t)b * p.qtiles * p.Cp + g * p.gw) * 16;
+    // partner images: window mode = the groups' gathered copies (one set per virtual item); pixel tiles = the packed map
+    const uint4* __restrict__ f1b = p.f1t + ((size_t)(p.window ? b : b % p.Bf) * p.qtiles * p.Cp + g * p.gw) * 16;
 
     auto touches = [&](int e) {
         const int4 bx = boxes[min(e, p.qtiles - 1)];
@@ -906,14 +939,19 @@ __global__ __launch_bounds__(256)
 void alt_bwd_reduce_kernel(AltBwdArgs p)
 {
     const int lane = threadIdx.x & 63, l = blockIdx.y;
-    const int eg = dout_exp(p, lane);
     const int e1 = range_exp16(wave_max128(fmaxf(p.maxpart[lane], p.maxpart[lane + 64])));
     const int nsplit = p.nsplit[l];
     if (nsplit <= 1) return;
     const int Hl = p.hl[l], Wl = p.wl[l], HWl = Hl * Wl, c4n = p.Cp >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.B * HWl * c4n) return;
-    const int c4 = (int)(idx % c4n), pix = (int)((idx / c4n) % HWl), b = (int)(idx / ((long long)c4n * HWl));
+    // an item's elements are padded to a multiple of 64 in the index space: a wave stays inside one virtual item, i.e. one
+    // lookup with its own range exponent (reduced with wave shuffles by all 64 lanes)
+    const long long per = ((long long)HWl * c4n + 63) & ~63ll;
+    const int b = (int)min(idx / per, (long long)p.B - 1);
+    const long long rem = idx - (long long)b * per;
+    const int eg = dout_exp(p, lane, b / p.Bf);
+    if (idx >= per * p.B || rem >= (long long)HWl * c4n) return;
+    const int c4 = (int)(rem % c4n), pix = (int)(rem / c4n);
     const int Y = pix / Wl, X = pix - Y * Wl, ttx = ttx_of(p, l), ttiles = ttiles_of(p, l);
     const int tt = (Y >> 3) * ttx + (X >> 3), u = (Y & 7) * 8 + (X & 7);
     const float4* __restrict__ src = (const float4*)(p.partial + p.poff[l]) + ((((size_t)b * ttiles + tt) * nsplit) * TQ + u) * c4n + c4;
@@ -934,11 +972,46 @@ void alt_bwd_reduce_kernel(AltBwdArgs p)
         }
 }
 
+// Several lookups per call: every lookup's gradients land in staging arrays of the workspace (virtual batch item
+// k * Bf + b), this kernel adds them in lookup order -- the same float additions, in the same order, as nk single calls
+// with accumulate = 1 make in place.  V floats per thread; grid (ceil(max n / V / 256), arrays)
+struct KSumArgs {
+    const float* stage[RAFTCORR_MAX_LEVELS + 1];
+    float* out[RAFTCORR_MAX_LEVELS + 1];
+    long long n[RAFTCORR_MAX_LEVELS + 1];         // floats per lookup
+    int nk, accumulate;
+};
+
+template <int V>
+__global__ __launch_bounds__(256)
+void alt_bwd_ksum_kernel(KSumArgs a)
+{
+    const int arr = blockIdx.y;
+    const long long n = a.n[arr], i = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i >= n) return;
+    const float* __restrict__ st = a.stage[arr];
+    float* __restrict__ out = a.out[arr] + i;
+    float v[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = st[i + j];
+    if (a.accumulate) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] += out[j];
+    }
+    for (int k = 1; k < a.nk; ++k) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] += st[(long long)k * n + i + j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[j] = v[j];
+}
+
 struct BwdPlan {
     int Cp, qtx, qtiles, ngroups, gw;
     int nsplit[RAFTCORR_MAX_LEVELS], ttiles[RAFTCORR_MAX_LEVELS], seg[RAFTCORR_MAX_LEVELS + 1];
     size_t poff[RAFTCORR_MAX_LEVELS];                        // floats
     size_t off_boxes, off_wins, off_partial, bytes;
+    size_t off_stage1, off_stage2[RAFTCORR_MAX_LEVELS];       // several lookups per call: per-lookup gradients
     int lorder[RAFTCORR_MAX_LEVELS];
     bool any_split;
     // window mode
@@ -946,15 +1019,17 @@ struct BwdPlan {
     size_t off_groups, off_dg, off_f1g;
 };
 
-BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
+// B: the virtual batch nk * Bf (nk lookups of Bf frame pairs per call)
+BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window, int nk = 1)
 {
     BwdPlan pl = {};
+    const int Bf = B / nk;
     pl.Cp = (C + 31) / 32 * 32;
     pl.qtx = (W + QW - 1) / QW;
     const int ptiles = pl.qtx * ((H + QH - 1) / QH);         // 8x8 pixel tiles
     pl.qtiles = ptiles;
     if (window) {
-        pl.gp = alt_groups_plan(B, H, W);
+        pl.gp = alt_groups_plan(Bf, H, W);
         pl.qtiles = pl.gp.gmax;
     }
     // Channels per workgroup.  GW: the G image of a step is built once and multiplied with two partner slices (half the
@@ -966,7 +1041,9 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
     pl.seg[0] = window ? B * pad8((long long)pl.qtiles * pl.ngroups) : pad8((long long)B * pl.qtiles * pl.ngroups);
     // partners per split workgroup: finer where the query tiles alone do not fill the chip twice over and the launch's tail
     // counts (KITTI: 8 against 12: -1 us on top of the order below; 1080p: 12 against 8: -1 .. 3 % less reduce traffic)
-    int splitf = (long long)B * ptiles * pl.ngroups < 512 ? 8 : 12;
+    // (a function of ONE lookup's geometry, not of the virtual batch: the split sizes decide the order of the partial sums,
+    // and a lookup's gradients must not depend on how many lookups share its call)
+    int splitf = (long long)Bf * ptiles * ((pl.Cp + CG - 1) / CG) < 512 ? 8 : 12;
 #if defined(RC_LAB)
     if (const char* e = getenv("RC_SPLITF")) splitf = atoi(e);
 #endif
@@ -1000,15 +1077,19 @@ BwdPlan make_plan(int B, int H, int W, int C, int L, int r, bool window)
         pl.seg[i + 1] = pl.seg[i] + pad8((long long)B * pl.ttiles[l] * pl.nsplit[l] * pl.ngroups);
     }
     auto up = [](size_t n) { return (n + 255) / 256 * 256; };
-    pl.off_boxes = DMAXP * sizeof(float);                    // in front: partial maxima of |dout|
+    pl.off_boxes = up((size_t)nk * DMAXP * sizeof(float));   // in front: partial maxima of |dout| per lookup
     pl.off_wins = up(pl.off_boxes + sizeof(int4) * (size_t)B * L * pl.qtiles);
     pl.off_partial = up(pl.off_wins + sizeof(int4) * (size_t)B * L * pl.qtiles * TQ);
     size_t end = up(pl.off_partial + pf * sizeof(float));
     if (window) {
         const int rd2 = (2 * r + 1) * (2 * r + 1);
-        pl.off_groups = end; end = up(end + pl.gp.bytes);      // (used when the caller brings no groups of its own)
+        pl.off_groups = end; end = up(end + (size_t)nk * pl.gp.bytes);     // (for lookups whose groups the caller does not bring)
         pl.off_dg = end;     end = up(end + sizeof(float) * (size_t)B * L * pl.qtiles * rd2 * TQ);
         pl.off_f1g = end;    end = up(end + (size_t)B * pl.qtiles * pl.Cp * 256);
+    }
+    if (nk > 1) {
+        pl.off_stage1 = end; end = up(end + sizeof(float) * (size_t)B * H * W * C);
+        for (int l = 0; l < L; ++l) { pl.off_stage2[l] = end; end = up(end + sizeof(float) * (size_t)B * (H >> l) * (W >> l) * C); }
     }
     pl.bytes = end;
     return pl;
@@ -1096,66 +1177,82 @@ int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const f
     return launch_alt_pack_tiles_set(&fmap, &H, &W, &maxpart, &packed, 1, B, C, s);
 }
 
-size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window)
+size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window, int nk)
 {
-    return make_plan(B, H, W, C, L, r, window).bytes;
+    return make_plan(B * std::max(nk, 1), H, W, C, L, r, window, std::max(nk, 1)).bytes;
 }
 
-// f1p_window != nullptr selects window mode: f1t is ignored, the tile-major partner images of fmap1 are gathered per
-// call for the query groups from the forward pass' packed copy f1p_window.  groups: the group buffer of the same
-// coordinates as launch_alt_groups left it (the forward pass of the lookup builds one), or nullptr: built here
-int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
-                            int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window, const void* groups)
+// nk lookups of the same B frame pairs in one call (1 <= nk <= ALT_KMAX): coords / douts (/ groups) are HOST arrays of nk
+// device pointers.  window: f1 is the forward pass' packed copy of fmap1 (the tile-major partner images are gathered per
+// call for the query groups) and groups[k] the group buffer of lookup k as launch_alt_groups left it, or nullptr: built
+// here; else f1 is the tile-major copy.  df1 / df2 receive (accumulate: are added) the SUM over the lookups, added in
+// array order.
+int launch_alt_lookup_bwd16_many(const void* f1, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
+                                 int r, int nk, const float* const* coords, const float* const* douts, const void* const* groups,
+                                 bool window, float* df1, float* const* df2, int accumulate,
+                                 void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (r > 7) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: radius %d > 7", r);
-    const bool window = f1p_window != nullptr;
-    const BwdPlan pl = make_plan(B, H, W, C, L, r, window);
+    if (nk < 1 || nk > ALT_KMAX) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: %d lookups per call (1 .. %d)", nk, ALT_KMAX);
+    if ((long long)B * nk > 65535) return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d lookups x batch %d is too large", nk, B);
+    const int VB = B * nk;
+    const BwdPlan pl = make_plan(VB, H, W, C, L, r, window, nk);
     if (!workspace || workspace_bytes < pl.bytes)
         return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace of %zu bytes needed, %zu given", pl.bytes, workspace_bytes);
     if (((uintptr_t)workspace & 255) != 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: workspace must be 256-byte aligned");
-    if ((long long)pl.seg[L] <= 0 || (size_t)B * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31) ||
+    if ((long long)pl.seg[L] <= 0 || (size_t)VB * pl.qtiles * pl.Cp * 16 >= ((size_t)1 << 31) ||
         (window && ((size_t)H * W * (pl.Cp / 32) * 8 >= ((size_t)1 << 31) ||
-                    (size_t)B * L * pl.qtiles * (2 * r + 1) * (2 * r + 1) * TQ >= ((size_t)1 << 31))))
-        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
+                    (size_t)VB * L * pl.qtiles * (2 * r + 1) * (2 * r + 1) * TQ >= ((size_t)1 << 31))))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d x %d lookups is too large", B, H, W, C, nk);
     AltBwdArgs a = {};
-    a.f1t = (const uint4*)f1t;
+    a.f1t = (const uint4*)f1;
+    a.nk = nk; a.Bf = B; a.window = window;
+    float* stage1 = nk > 1 ? (float*)((char*)workspace + pl.off_stage1) : df1;
     for (int l = 0; l < L; ++l) {
-        a.f2t[l] = (const uint4*)f2t[l]; a.hl[l] = H >> l; a.wl[l] = W >> l; a.df2[l] = df2[l];
+        a.f2t[l] = (const uint4*)f2t[l]; a.hl[l] = H >> l; a.wl[l] = W >> l;
+        a.df2[l] = nk > 1 ? (float*)((char*)workspace + pl.off_stage2[l]) : df2[l];
         a.poff[l] = (long long)pl.poff[l]; a.nsplit[l] = pl.nsplit[l];
     }
     for (int l = 0; l <= L; ++l) a.seg[l] = pl.seg[l];
     for (int l = 0; l < L; ++l) a.lorder[l] = pl.lorder[l];
-    a.coords = coords; a.dout = dout; a.maxpart = maxpart; a.df1 = df1;
+    for (int k = 0; k < nk; ++k) {
+        if (!coords[k] || !douts[k]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd: null coords / dout of lookup %d", k);
+        a.coords_k[k] = coords[k]; a.dout_k[k] = douts[k];
+    }
+    a.maxpart = maxpart; a.df1 = stage1;
     a.dmax = (const float*)workspace;
     a.boxes = (int4*)((char*)workspace + pl.off_boxes);
     a.wins = (int4*)((char*)workspace + pl.off_wins);
     a.partial = (float*)((char*)workspace + pl.off_partial);
-    a.B = B; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
+    a.B = VB; a.C = C; a.Cp = pl.Cp; a.H = H; a.W = W; a.L = L; a.r = r;
     a.qtx = pl.qtx; a.qtiles = pl.qtiles; a.ngroups = pl.ngroups; a.gw = pl.gw;
     a.sqrt_c = sqrtf((float)C);
-    a.accumulate = accumulate;
+    a.accumulate = nk > 1 ? 0 : accumulate;                   // (several lookups: the staging arrays are overwritten)
     const int rd2 = (2 * r + 1) * (2 * r + 1);
     int rc;
+    const void* f1p_window = nullptr;
     if (window) {
-        if (!groups) {
-            void* own = (char*)workspace + pl.off_groups;
-            if ((rc = launch_alt_groups(coords, B, H, W, own, pl.gp.bytes, s))) return rc;
-            groups = own;
-        } else if (((uintptr_t)groups & 255) != 0) {
-            return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: groups must be 256-byte aligned");
+        f1p_window = f1;
+        for (int k = 0; k < nk; ++k) {
+            const void* g = groups ? groups[k] : nullptr;
+            if (!g) {
+                void* own = (char*)workspace + pl.off_groups + (size_t)k * pl.gp.bytes;
+                if ((rc = launch_alt_groups(coords[k], B, H, W, own, pl.gp.bytes, s))) return rc;
+                g = own;
+            } else if (((uintptr_t)g & 255) != 0) {
+                return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_sorted: groups must be 256-byte aligned");
+            }
+            a.ngr_k[k] = (const int*)g;
+            a.qlist_k[k] = (const int*)((const char*)g + pl.gp.off_qlist);
         }
-        a.ngr = (int*)groups;
-        a.qlist = (int*)((char*)groups + pl.gp.off_qlist);
         a.dg = (float*)((char*)workspace + pl.off_dg);
-        uint4* f1g = (uint4*)((char*)workspace + pl.off_f1g);
-        a.f1t = f1g;
+        a.f1t = (const uint4*)((char*)workspace + pl.off_f1g);
     }
-    const long long ngather = window ? (long long)B * pl.qtiles * (pl.Cp / 32) : 0;
-    if ((long long)B * L * pl.qtiles + DMAXP + ngather >= ((long long)1 << 31))
-        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d is too large", B, H, W, C);
-    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3((unsigned)(B * L * pl.qtiles + DMAXP + ngather)), dim3(window ? 256 : 64), 0, s, a,
-                       B * L * pl.qtiles, (size_t)B * L * rd2 * H * W, (const uint4*)f1p_window);
+    const long long ngather = window ? (long long)VB * pl.qtiles * (pl.Cp / 32) : 0;
+    if ((long long)VB * L * pl.qtiles + (long long)nk * DMAXP + ngather >= ((long long)1 << 31))
+        return fail(RAFTCORR_EUNSUPPORTED, "alt_lookup_bwd: %d x %d x %d x %d x %d lookups is too large", B, H, W, C, nk);
+    hipLaunchKernelGGL(alt_bwd_pre_kernel, dim3((unsigned)(VB * L * pl.qtiles + nk * DMAXP + ngather)), dim3(window ? 256 : 64), 0, s,
+                       a, VB * L * pl.qtiles, (size_t)B * L * rd2 * H * W, (const uint4*)f1p_window);
     rc = check_launch("alt_bwd_pre_kernel");
     if (rc) return rc;
     const size_t sm = (size_t)(IMG_A + IMG_B) * sizeof(uint4) + (size_t)TQ * std::max(rd2, 96) * sizeof(float);
@@ -1169,12 +1266,38 @@ int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float
     if (e != hipSuccess) return fail(RAFTCORR_ELAUNCH, "alt_lookup_bwd: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(alt_bwd_kernel, dim3(pl.seg[L]), dim3(256), sm, s, a);
     rc = check_launch("alt_bwd_kernel");
-    if (rc || !pl.any_split) return rc;
-    size_t most = 0;
-    for (int l = 0; l < L; ++l)
-        if (pl.nsplit[l] > 1) most = std::max(most, (size_t)B * (H >> l) * (W >> l) * (pl.Cp / 4));
-    hipLaunchKernelGGL(alt_bwd_reduce_kernel, dim3((unsigned)((most + 255) / 256), L), dim3(256), 0, s, a);
-    return check_launch("alt_bwd_reduce_kernel");
+    if (rc) return rc;
+    if (pl.any_split) {
+        size_t most = 0;
+        for (int l = 0; l < L; ++l)
+            if (pl.nsplit[l] > 1) most = std::max(most, (size_t)VB * ((((size_t)(H >> l) * (W >> l) * (pl.Cp / 4)) + 63) / 64 * 64));
+        hipLaunchKernelGGL(alt_bwd_reduce_kernel, dim3((unsigned)((most + 255) / 256), L), dim3(256), 0, s, a);
+        if ((rc = check_launch("alt_bwd_reduce_kernel"))) return rc;
+    }
+    if (nk == 1) return RAFTCORR_OK;
+    KSumArgs ks = {};
+    ks.nk = nk; ks.accumulate = accumulate;
+    ks.stage[0] = stage1; ks.out[0] = df1; ks.n[0] = (long long)B * H * W * C;
+    long long most = ks.n[0];
+    bool vec = ((uintptr_t)df1 & 15) == 0 && ks.n[0] % 4 == 0;
+    for (int l = 0; l < L; ++l) {
+        ks.stage[l + 1] = a.df2[l]; ks.out[l + 1] = df2[l]; ks.n[l + 1] = (long long)B * (H >> l) * (W >> l) * C;
+        most = std::max(most, ks.n[l + 1]);
+        vec = vec && ((uintptr_t)df2[l] & 15) == 0 && ks.n[l + 1] % 4 == 0;
+    }
+    if (vec) hipLaunchKernelGGL(alt_bwd_ksum_kernel<4>, dim3((unsigned)((most / 4 + 255) / 256), L + 1), dim3(256), 0, s, ks);
+    else     hipLaunchKernelGGL(alt_bwd_ksum_kernel<1>, dim3((unsigned)((most + 255) / 256), L + 1), dim3(256), 0, s, ks);
+    return check_launch("alt_bwd_ksum_kernel");
+}
+
+// one lookup: f1p_window != nullptr selects window mode (f1t is ignored); groups: see above
+int launch_alt_lookup_bwd16(const void* f1t, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
+                            int r, const float* coords, const float* dout, float* df1, float* const* df2, int accumulate,
+                            void* workspace, size_t workspace_bytes, hipStream_t s, const void* f1p_window, const void* groups)
+{
+    const bool window = f1p_window != nullptr;
+    return launch_alt_lookup_bwd16_many(window ? f1p_window : f1t, f2t, maxpart, B, H, W, C, L, r, 1, &coords, &dout, &groups, window,
+                                        df1, df2, accumulate, workspace, workspace_bytes, s);
 }
 
 }  // namespace raftcorr

@@ -60,7 +60,7 @@ struct TileQ {
     int box[4];
 };
 
-// Args needs: coords (B,2,H,W), hl[], wl[], H, W, L, r, band (tiles per XCD band).  Workgroup id -> (XCD band, tile,
+// Args needs: hl[], wl[], H, W, L, r, band (tiles per XCD band).  Workgroup id -> (XCD band, tile,
 // level, batch): each XCD (id mod 8) owns a band of tiles, whose part of the target maps stays in that XCD's L2.
 struct Tile16 {
     int b, l, ty0, tx0, Hl, Wl, HWl;
@@ -70,9 +70,11 @@ struct Tile16 {
 
 // window origins of the tile's queries at level t.l + the bounding box of their in-level parts (wave 0: one lane
 // per query).  t.b, t.l, t.ty0, t.tx0 must be set; contains a barrier (every thread of the workgroup calls it).
-// qsrc: nullptr = the 8x8 pixel tile at (t.ty0, t.tx0); else 64 query pixel indices (-1 = empty slot).
+// cb: the coordinates of batch item t.b, (2, H, W).  qsrc: nullptr = the 8x8 pixel tile at (t.ty0, t.tx0); else 64
+// query pixel indices (-1 = empty slot).
 template <class Args>
-__device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile16& t, const int* __restrict__ qsrc = nullptr)
+__device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile16& t, const float* __restrict__ cb,
+                                                 const int* __restrict__ qsrc = nullptr)
 {
     t.Hl = p.hl[t.l]; t.Wl = p.wl[t.l]; t.HWl = t.Hl * t.Wl;
     const int tid = threadIdx.x;
@@ -85,7 +87,7 @@ __device__ __forceinline__ void tile_level_setup(const Args& p, TileQ& sh, Tile1
         float fx = 0.f, fy = 0.f;
         if (valid) {
             const size_t P = (size_t)p.H * p.W, q = (size_t)pix;
-            const float* c = p.coords + (size_t)t.b * 2 * P + q;
+            const float* c = cb + q;
             const float s = 1.0f / (float)(1 << t.l);        // exact power of two == coords / 2**l (corr.py:86)
             int x0, y0;
             split_coord(c[0] * s, x0, fx);

@@ -151,14 +151,14 @@ void alt_fwd16_kernel(AltFwdArgs p)
             t.live = j < bandl && tile < nt;
             if (!t.live) return;                             // whole workgroup
             t.ty0 = t.tx0 = 0;
-            tile_level_setup(p, sh, t, p.qlist + ((size_t)t.b * p.gmax + tile) * 64);
+            tile_level_setup(p, sh, t, p.coords + (size_t)t.b * 2 * p.H * p.W, p.qlist + ((size_t)t.b * p.gmax + tile) * 64);
         } else {
             const int tiles_x = (p.W + QW - 1) / QW, tile = xcd * p.band + j;
             t.live = tile < tiles_x * ((p.H + QH - 1) / QH);
             if (!t.live) return;                             // whole workgroup
             t.ty0 = (tile / tiles_x) * QH;
             t.tx0 = (tile % tiles_x) * QW;
-            tile_level_setup(p, sh, t);
+            tile_level_setup(p, sh, t, p.coords + (size_t)t.b * 2 * p.H * p.W);
         }
     }
     const int nkc = p.Cp / KC;

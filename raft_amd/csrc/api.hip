@@ -483,6 +483,40 @@ int raftcorr_alt_lookup_bwd_sorted(const void* packed1, const void* const* tiles
                                    (hipStream_t)stream, packed1, groups);
 }
 
+int64_t raftcorr_alt_lookup_bwd_many_workspace_bytes(int B, int H, int W, int C, int num_levels, int radius, int n_lookups,
+                                                     int window)
+{
+    if (B < 1 || H < 1 || W < 1 || C < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS || radius < 0 ||
+        n_lookups < 1 || n_lookups > RAFTCORR_ALT_MAX_LOOKUPS) return 0;
+    return (int64_t)alt_lookup_bwd_workspace_bytes(B, H, W, C, num_levels, radius, window != 0, n_lookups);
+}
+
+int raftcorr_alt_lookup_bwd_many(const void* fmap1_packed, const void* const* tiles2_levels, const float* scales,
+                                 int B, int H, int W, int C, int num_levels, int radius, int n_lookups,
+                                 const float* const* coords, const float* const* douts, const void* const* groups, int window,
+                                 float* dfmap1, float* const* dfmap2_levels, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, void* stream)
+{
+    int rc = check_dims("alt_lookup_bwd_many", B, H, W);
+    if (rc) return rc;
+    if (!fmap1_packed || !tiles2_levels || !scales || !coords || !douts || !dfmap1 || !dfmap2_levels)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: null pointer");
+    if (C < 1 || radius < 0) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: C=%d radius=%d", C, radius);
+    if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
+    if (n_lookups < 1 || n_lookups > RAFTCORR_ALT_MAX_LOOKUPS)
+        return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: n_lookups = %d not in [1, %d]", n_lookups, RAFTCORR_ALT_MAX_LOOKUPS);
+    for (int l = 0; l < num_levels; ++l) {
+        if ((H >> l) < 1 || (W >> l) < 1) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: level %d of a %d x %d map is empty", l, H, W);
+        if (!tiles2_levels[l] || !dfmap2_levels[l]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: level %d pointer is null", l);
+    }
+    for (int k = 0; k < n_lookups; ++k)
+        if (!coords[k] || !douts[k]) return fail(RAFTCORR_EINVAL, "alt_lookup_bwd_many: coords / dout of lookup %d is null", k);
+    return launch_alt_lookup_bwd16_many(fmap1_packed, tiles2_levels, scales, B, H, W, C, num_levels, radius, n_lookups, coords, douts,
+                                        window ? groups : nullptr, window != 0, dfmap1, dfmap2_levels, accumulate, workspace,
+                                        workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, (hipStream_t)stream);
+}
+
 int64_t raftcorr_alt_prepare_workspace_bytes(int B, int C, int H, int W, int num_levels)
 {
     if (B < 1 || C < 1 || H < 1 || W < 1 || num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS) return 0;

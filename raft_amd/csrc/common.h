@@ -69,7 +69,11 @@ size_t alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int L);
 int launch_maxabs1(const float* x, size_t n, float* out, hipStream_t s);
 size_t alt_tiles_bytes(int B, int C, int H, int W);
 int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
-size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window = false);
+size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window = false, int nk = 1);
+int launch_alt_lookup_bwd16_many(const void* f1, const void* const* f2t, const float* maxpart, int B, int H, int W, int C, int L,
+                                 int r, int nk, const float* const* coords, const float* const* douts, const void* const* groups,
+                                 bool window, float* df1, float* const* df2, int accumulate,
+                                 void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t alt_prepare_workspace_bytes(int B, int C, int H, int W, int L);
 int launch_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int H, int W, int L, float* scales,
                        void* packed1, void* const* packed2, void* tiles1, void* const* tiles2,

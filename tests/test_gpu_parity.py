@@ -906,6 +906,36 @@ def test_on_the_fly_backward_takes_the_forward_call_s_groups(dev):
             assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("tiles", ["pixel", "window"])
+def test_on_the_fly_deferred_backward_matches_per_lookup(dev, tiles):
+    """AlternateCorrBlock(backward="deferred") keeps every lookup's (coords, d(out), groups) and lets the features' node
+    run raftcorr_alt_lookup_bwd_many once (lookups x batch items as one virtual batch, per-lookup gradients added in the
+    order the backward calls arrived); backward="per_lookup" runs the kernels in every lookup's backward call and adds
+    in place.  Same additions in the same order: the feature gradients must agree to the last bit -- 3 lookups, 18
+    lookups (more than one library call holds: the list is cut at 16), a batch of 2, odd sizes, C not a multiple of 4
+    (the scalar path of the summing kernel), and a second pass over a retained graph."""
+    from raft_amd import AlternateCorrBlock
+    for (B, D, H, W, L, r, n) in ((2, 72, 30, 41, 3, 4, 3), (1, 33, 19, 23, 2, 3, 18), (1, 64, 47, 78, 4, 4, 5)):
+        rs = np.random.RandomState(B * 100 + n)
+        f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        base = np.stack([xx, yy], 0)[None].astype(np.float32)
+        cons = [_t(base + (0.5 + 0.7 * k) * rs.randn(B, 2, H, W).astype(np.float32), dev) for k in range(n)]
+        gouts = [_t((10.0 ** (k % 4 - 2)) * rs.randn(B, L * (2 * r + 1) ** 2, H, W).astype(np.float32), dev) for k in range(n)]
+        res = {}
+        for mode in ("per_lookup", "deferred"):
+            f1, f2 = _t(f1n, dev, True), _t(f2n, dev, True)
+            blk = AlternateCorrBlock(f1, f2, num_levels=L, radius=r, tiles=tiles, backward=mode)
+            outs = [blk(c) for c in cons]
+            torch.autograd.backward(outs, gouts, retain_graph=True)
+            g1 = (f1.grad.clone(), f2.grad.clone())
+            f1.grad = f2.grad = None
+            torch.autograd.backward(outs[:2], gouts[:2])                   # a second, shorter pass starts from new sums
+            res[mode] = g1 + (f1.grad.clone(), f2.grad.clone())
+        for a, b in zip(res["per_lookup"], res["deferred"]):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (tiles, B, D, H, W, n)
+
+
 def test_window_groups_match_a_numpy_model(dev):
     """The query groups raftcorr_alt_lookup_fwd_sorted leaves in its workspace, read back and compared with a numpy
     restatement of their definition (csrc/alt_bwd.hip): key = 8x8 level-0 cell of floor(coords) (one ring of cells
