@@ -300,10 +300,13 @@ class KittiAlt(Workload):
                                      compulsory_bytes=w["alt_bytes"], hbm_GBs=w["alt_bytes"] / fwd_us / 1e3,
                                      hbm_frac=w["alt_bytes"] / fwd_us / 1e3 / HBM_PEAK_GBS, traffic=tr.get("alt_fwd16_kernel"),
                                      traffic_source="profiles/" + tsrc, note=note),
-             "alt_bwd": mfma16_entry("alt_bwd_kernel (+ gathers, range pass, reduce; groups from the forward pass)", bwd_us, w["alt_bwd_flops"], 3,
+             "alt_bwd": mfma16_entry("raftcorr_alt_lookup_bwd_many, one call for the pair's lookups: alt_bwd_pre + alt_bwd_kernel + "
+                                     "alt_bwd_reduce + alt_bwd_ksum (per-lookup share; groups from the forward pass)", bwd_us,
+                                     w["alt_bwd_flops"], 3,
                                      compulsory_bytes=w["alt_bwd_bytes"], hbm_GBs=w["alt_bwd_bytes"] / bwd_us / 1e3,
                                      hbm_frac=w["alt_bwd_bytes"] / bwd_us / 1e3 / HBM_PEAK_GBS,
-                                     traffic=tr.get("alt_bwd_kernel"), traffic_source="profiles/" + tsrc, note=note)}
+                                     traffic=(tr.get("alt_bwd_kernel") or 0) // tr.get("alt_bwd_lookups_per_launch", 1) or None,
+                                     traffic_source="profiles/" + tsrc, note=note)}
         return k, ("alt_bwd" if bwd_us >= fwd_us else "alt_fwd")
 
 
