@@ -499,6 +499,29 @@ def extras_kitti(torch, wl, dev):
                 "alt_bwd_pre (windows, d(out) tiles, range pass, fmap1 gather) + alt_bwd + alt_bwd_reduce kernels (groups from the lookup's forward call)", tg,
                 w["alt_bwd_flops"], 3, hbm_GBs=w["alt_bwd_bytes"] / tg / 1e3,
                 hbm_frac=w["alt_bwd_bytes"] / tg / 1e3 / HBM_PEAK_GBS, **hb)
+        # the deferred backward pass: all lookups of the pair in ONE library call (what the timed step runs), groups of the
+        # forward calls, the step's own random walks
+        nl = len(wl.coords)
+        if nl <= _lib.ALT_MAX_LOOKUPS:
+            gws = []
+            for c in wl.coords:
+                g = torch.empty(swb, dtype=torch.uint8, device=dev)
+                lib.raftcorr_alt_lookup_fwd_sorted(blk._p1.data_ptr(), blk._p2ptrs, blk._scales.data_ptr(), B, H, W, D, LEVELS, RADIUS,
+                                                   c.data_ptr(), o.data_ptr(), g.data_ptr(), swb, stream)
+                gws.append(g)
+            for tag, window in (("window_groups", 1), ("pixel_tiles", 0)):
+                mb = lib.raftcorr_alt_lookup_bwd_many_workspace_bytes(B, H, W, D, LEVELS, RADIUS, nl, window)
+                mwork = torch.empty(mb, dtype=torch.uint8, device=dev)
+                cp, dp, gp = _lib.ptr_array(wl.coords), _lib.ptr_array(wl.gouts), _lib.ptr_array(gws)
+                f1 = gblk._p1 if window else gblk._t1
+                tm = ev_time_us(torch, lambda: lib.raftcorr_alt_lookup_bwd_many(
+                    f1.data_ptr(), gblk._t2ptrs, gblk._scales.data_ptr(), B, H, W, D, LEVELS, RADIUS, nl, cp, dp, gp if window else None,
+                    window, d1.data_ptr(), dlv, 0, mwork.data_ptr(), mb, stream), reps=10, warm=2)
+                out["alt_bwd_many_%s_per_lookup" % tag] = mfma16_entry(
+                    "raftcorr_alt_lookup_bwd_many over the step's %d lookups (alt_bwd_pre + alt_bwd + alt_bwd_reduce + alt_bwd_ksum), "
+                    "time / lookups" % nl, tm / nl, w["alt_bwd_flops"], 3, compulsory_bytes=w["alt_bwd_bytes"],
+                    hbm_GBs=w["alt_bwd_bytes"] / (tm / nl) / 1e3, hbm_frac=w["alt_bwd_bytes"] / (tm / nl) / 1e3 / HBM_PEAK_GBS)
+                del mwork
     # the whole step with 8x8 pixel tiles in the forward pass (the default of AlternateCorrBlock: flow fields are smooth)
     wl.tiles = "pixel"
     try:
