@@ -671,8 +671,16 @@ def _alt_backward_many(st, rec):
     B, C, H, W = st.shape
     L, window = st.L, blk.tiles == "window"
     f1 = blk._p1 if window else blk._t1
-    for i in range(0, len(rec), _lib.ALT_MAX_LOOKUPS):
-        part = rec[i:i + _lib.ALT_MAX_LOOKUPS]
+    # lookups per call: as many as the library takes, fewer for very large maps (32-bit offsets inside the kernels'
+    # workspace: items x levels x group slots x window cells x 64 < 2^31; and a workspace of at most 8 GiB)
+    rd2 = (2 * blk.radius + 1) ** 2
+    slots = ((H * W + 63) // 64 + ((W + 7) // 8 + 2) * ((H + 7) // 8 + 2)) if window else ((W + 7) // 8) * ((H + 7) // 8)
+    per_call = max(1, min(_lib.ALT_MAX_LOOKUPS, (2 ** 31 - 1) // max(B * L * slots * rd2 * 64, B * slots * ((C + 31) // 32 * 32) * 16)))
+    while per_call > 1 and lib.raftcorr_alt_lookup_bwd_many_workspace_bytes(B, H, W, C, L, blk.radius, per_call,
+                                                                             1 if window else 0) > (8 << 30):
+        per_call //= 2
+    for i in range(0, len(rec), per_call):
+        part = rec[i:i + per_call]
         acc, first = st.buffers()
         n = len(part)
         nbytes = lib.raftcorr_alt_lookup_bwd_many_workspace_bytes(B, H, W, C, L, blk.radius, n, 1 if window else 0)

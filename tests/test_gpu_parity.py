@@ -915,7 +915,8 @@ def test_on_the_fly_deferred_backward_matches_per_lookup(dev, tiles):
     lookups (more than one library call holds: the list is cut at 16), a batch of 2, odd sizes, C not a multiple of 4
     (the scalar path of the summing kernel), and a second pass over a retained graph."""
     from raft_amd import AlternateCorrBlock
-    for (B, D, H, W, L, r, n) in ((2, 72, 30, 41, 3, 4, 3), (1, 33, 19, 23, 2, 3, 18), (1, 64, 47, 78, 4, 4, 5)):
+    for (B, D, H, W, L, r, n) in ((2, 72, 30, 41, 3, 4, 3), (1, 33, 19, 23, 2, 3, 18), (1, 64, 47, 78, 4, 4, 5),
+                                  (1, 32, 136, 240, 4, 4, 3)):
         rs = np.random.RandomState(B * 100 + n)
         f1n, f2n = rs.randn(B, D, H, W).astype(np.float32), rs.randn(B, D, H, W).astype(np.float32)
         yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
