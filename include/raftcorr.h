@@ -349,8 +349,9 @@ int raftcorr_alt_lookup_bwd_many(const void* fmap1_packed, const void* const* ti
  * its constructor -- the avg_pool2d chain -- plus the packed copies the kernels above read; and its adjoint).
  *   raftcorr_alt_prepare       = raftcorr_alt_scales + the fmap2 pyramid (avg_pool2d(., 2, stride=2) chain, levels
  *                         1 .. L-1; same summation order as torch's kernel) + raftcorr_alt_pack of fmap1 and of every
- *                         level (+ raftcorr_alt_pack_tiles of the same maps when tiles1 / tiles2_levels are not NULL:
- *                         needed for raftcorr_alt_lookup_bwd only).  packed2_levels / tiles2_levels: HOST arrays of L
+ *                         level (+ raftcorr_alt_pack_tiles of the fmap2 levels when tiles2_levels is not NULL, and of
+ *                         fmap1 when tiles1 is not NULL: the backward calls read them; the window-group calls take
+ *                         packed1 instead of tiles1, so tiles1 may be NULL with tiles2_levels given).  packed2_levels / tiles2_levels: HOST arrays of L
  *                         DEVICE buffers of raftcorr_alt_packed_bytes / raftcorr_alt_tiles_bytes(B, C, H>>l, W>>l) bytes;
  *                         workspace: raftcorr_alt_prepare_workspace_bytes(...) bytes, 256-byte aligned (receives the
  *                         pooled float32 levels; don't-care afterwards).

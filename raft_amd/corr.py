@@ -705,7 +705,7 @@ class _AltFeatures(torch.autograd.Function):
     def forward(ctx, state, fmap1, fmap2):
         ctx.state = state
         ctx.set_materialize_grads(False)
-        return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
+        return torch.empty(1, dtype=torch.float32, device=fmap1.device)    # (a graph edge; nobody reads the value)
 
     @staticmethod
     @once_differentiable
@@ -831,7 +831,7 @@ class AlternateCorrBlock:
         dims = [(H, W)] + [(H >> l, W >> l) for l in range(num_levels)]
         sizes = [1024] + [lib.raftcorr_alt_packed_bytes(B, C, h, w) for h, w in dims]
         if self._grad:
-            sizes += [lib.raftcorr_alt_tiles_bytes(B, C, h, w) for h, w in dims]
+            sizes += [lib.raftcorr_alt_tiles_bytes(B, C, h, w) if i or tiles == "pixel" else 0 for i, (h, w) in enumerate(dims)]
         sizes.append(lib.raftcorr_alt_prepare_workspace_bytes(B, C, H, W, num_levels))
         offs = [0]
         for n in sizes:
@@ -846,11 +846,13 @@ class AlternateCorrBlock:
         if self._grad:
             self._t1, self._t2 = parts[1 + n], parts[2 + n:1 + 2 * n]
             self._t2ptrs = _lib.ptr_array(self._t2)
+            if tiles != "pixel":                                # the window-group backward gathers fmap1 from _p1 per call
+                self._t1 = None
         work = parts[-1]
         with _guard(f1):
             _lib.check(lib.raftcorr_alt_prepare(f1.data_ptr(), f2.data_ptr(), B, C, H, W, num_levels, self._scales.data_ptr(),
                                                 self._p1.data_ptr(), self._p2ptrs,
-                                                self._t1.data_ptr() if self._grad else None, self._t2ptrs,
+                                                self._t1.data_ptr() if self._t1 is not None else None, self._t2ptrs,
                                                 work.data_ptr(), work.numel(), _stream(f1)), "alt_prepare")
         if self._grad:
             self._gstate = _AltGradState(self._shape, num_levels, dev)

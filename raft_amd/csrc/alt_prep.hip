@@ -146,11 +146,14 @@ int launch_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, int
     int hs[RAFTCORR_MAX_LEVELS + 1] = {H}, ws[RAFTCORR_MAX_LEVELS + 1] = {W};
     for (int l = 0; l < L; ++l) {
         maps[l + 1] = level[l]; mp[l + 1] = scales + 128; dst[l + 1] = packed2[l]; hs[l + 1] = H >> l; ws[l + 1] = W >> l;
-        if (tiles1) dstt[l + 1] = tiles2[l];
+        if (tiles2) dstt[l + 1] = tiles2[l];
     }
     rc = launch_alt_pack_set(maps, hs, ws, mp, dst, L + 1, B, C, s);
-    if (rc || !tiles1) return rc;
-    return launch_alt_pack_tiles_set(maps, hs, ws, mp, dstt, L + 1, B, C, s);
+    if (rc || !tiles2) return rc;
+    // tile-major copies for the backward pass: the fmap2 pyramid, and fmap1 when asked for (the window-group backward
+    // gathers its fmap1 images from packed1 per call and does not read a tile-major copy)
+    if (tiles1) return launch_alt_pack_tiles_set(maps, hs, ws, mp, dstt, L + 1, B, C, s);
+    return launch_alt_pack_tiles_set(maps + 1, hs + 1, ws + 1, mp + 1, dstt + 1, L, B, C, s);
 }
 
 int launch_alt_features_bwd(const float* d1, const float* const* d2, int B, int C, int H, int W, int L,

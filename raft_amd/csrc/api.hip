@@ -532,8 +532,8 @@ int raftcorr_alt_prepare(const float* fmap1, const float* fmap2, int B, int C, i
     if (rc) return rc;
     if (!fmap1 || !fmap2 || !scales || !packed1 || !packed2_levels || C < 1)
         return fail(RAFTCORR_EINVAL, "alt_prepare: bad argument");
-    if ((tiles1 == nullptr) != (tiles2_levels == nullptr))
-        return fail(RAFTCORR_EINVAL, "alt_prepare: tiles1 and tiles2_levels go together");
+    if (tiles1 && !tiles2_levels)
+        return fail(RAFTCORR_EINVAL, "alt_prepare: tiles1 without tiles2_levels");
     if (num_levels < 1 || num_levels > RAFTCORR_MAX_LEVELS)
         return fail(RAFTCORR_EINVAL, "alt_prepare: num_levels = %d not in [1, %d]", num_levels, RAFTCORR_MAX_LEVELS);
     for (int l = 0; l < num_levels; ++l) {
