@@ -258,7 +258,7 @@ class _BuildPyramid(torch.autograd.Function):
         ctx.save_for_backward(fmap1, fmap2)
         ctx.pyr = pyr
         ctx.set_materialize_grads(False)
-        anchor = torch.zeros(1, dtype=torch.float32, device=fmap1.device)
+        anchor = torch.empty(1, dtype=torch.float32, device=fmap1.device)     # (a graph edge; nobody reads the value)
         return flat, anchor
 
     @staticmethod

@@ -18,6 +18,7 @@
 // arithmetic, and padding columns carry exact zeros (lookups never write them), so the fold
 // is an elementwise pass and the contractions run over the padded column range unchecked.
 #include "common.h"
+#include <limits.h>
 #include <algorithm>
 #include <stdlib.h>
 
@@ -189,6 +190,14 @@ struct GemmArgs {
     int vecA, vecB;      // 16-byte loads legal (alignment + extents)
     const float* maxA;   // fp16x2 kernel: [128] partial maxima of |A| and of |B| (range scaling)
     const float* maxB;
+    // Columns of the folded gradient that are padding only (layout.h: the lower 4x16 half of every patch of the bottom
+    // patch row when H % 8 is 1..4 -- cells 64..127 of those patches; 50x90: 384 of 5376 columns).  Both are "off" at
+    // INT_MAX.  16-bit kernels only; the fp32 fallback multiplies the zeros.
+    int kskip_from;      // K = columns (dF1): K indices >= this are skipped where (k >> 6) & 1
+    int nremap_from;     // N = columns (dF2): N tiles >= this hold the upper halves of TWO patches (cells 0..63 each)
+    // dF2 without split planes: the epilogue stores column p (patch-tile order) at its pixel, C = dF2 [M][H * W] itself
+    // (no column-order copy, no corr_cols_scatter_back launch).  Off at scat_h = 0.
+    int scat_h, scat_w, scat_pw;
 };
 
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
@@ -424,8 +433,15 @@ void gemm_bf16x3_kernel(GemmArgs p)
     int nt, mt;
     gemm_tile_of_block(nt, mt);
     const int n0 = nt * TN, m0 = mt * TM;
+    // column bases of the tile's two 64-column halves (n-contiguous B only: the tiles past nremap_from pair the
+    // upper halves of two bottom-row patches, an odd one out has no second half)
+    int n0a = n0, n0b = n0 + 64;
+    if (!B_K_CONTIG && nt >= p.nremap_from) { n0a = (2 * nt - p.nremap_from) * TN; n0b = n0a + TN; }
     const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
-    const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
+    const int kend = min(p.K, (ks + 1) * p.kper);
+    // first K tile at or after k that is not all padding (skipped blocks are the odd 64-blocks past kskip_from)
+    auto adv = [&](int k) { return (B_K_CONTIG && k >= p.kskip_from && ((k >> 6) & 1)) ? ((k >> 6) + 1) << 6 : k; };
+    const int kbeg = adv(ks * p.kper);
     const int M = p.M, N = p.N;
     const float* __restrict__ Ab = p.A + bz * p.sA;
     const float* __restrict__ Bb = p.B + bz * p.sB;
@@ -470,15 +486,15 @@ void gemm_bf16x3_kernel(GemmArgs p)
                 }
             }
         } else {
-            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)k0 * p.ldb + n0);
-            const int col = tid & 127;
+            const int col = (tid & 64) ? n0b + (tid & 63) : n0a + (tid & 63);
+            const __amdgpu_buffer_rsrc_t rs = desc(Bb + (size_t)k0 * p.ldb);
 #pragma unroll
             for (int i = 0; i < SL; ++i) {
                 const int kg = (tid >> 7) + 2 * i;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = 8 * kg + j;
-                    const bool ok = k0 + k < kend && n0 + col < N;
+                    const bool ok = k0 + k < kend && col < N;
                     xb[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                         rs, ok ? (unsigned)(((size_t)k * p.ldb + col) * 4) : GOOB, 0, 0));
                 }
@@ -523,11 +539,12 @@ void gemm_bf16x3_kernel(GemmArgs p)
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     const int kh = lane >> 5, l31 = lane & 31;
     if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    for (int k0 = kbeg, kn; k0 < kend; k0 = kn) {
+        kn = adv(k0 + TK);
         __syncthreads();
         lstore();
         __syncthreads();
-        if (k0 + TK < kend) gload(k0 + TK);
+        if (kn < kend) gload(kn);
 #pragma unroll
         for (int st = 0; st < TK / 16; ++st) {
             // piece of B outermost, small products first: lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi
@@ -561,11 +578,21 @@ void gemm_bf16x3_kernel(GemmArgs p)
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int n = n0 + wn * 64 + b * 32 + l31;
+            int n = (wn ? n0b : n0a) + b * 32 + l31;
+            bool n_ok = n < N;
+            if (!B_K_CONTIG && p.scat_h) {          // column of the volume -> pixel (inverse of layout.h level_pos, level 0)
+                const int patch = n >> 7, t = (n >> 5) & 3, j = n & 31;
+                const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
+                const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
+                const int py = patch / p.scat_pw;
+                const int y = py * PATCH_H + (t >> 1) * 4 + dy, x = (patch - py * p.scat_pw) * PATCH_W + (t & 1) * 8 + dx;
+                n_ok = n_ok && y < p.scat_h && x < p.scat_w;
+                n = y * p.scat_w + x;
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                if (m < M && n < N) {
+                if (m < M && n_ok) {
                     C[(size_t)m * p.ldc + n] = F16 ? acc[a][b][reg] * unscale : acc[a][b][reg];
                 }
             }
@@ -623,7 +650,7 @@ static int run_gemm(GemmArgs a, int batch, float* partial, const char* what, hip
     a.vecA = (a.lda % 4 == 0) && (a.K % 4 == 0) && (((uintptr_t)a.A | (a.sA * 4)) % 16 == 0);
     a.vecB = (a.ldb % 4 == 0) && ((B_K_CONTIG ? a.K : a.N) % 4 == 0) && (((uintptr_t)a.B | (a.sB * 4)) % 16 == 0);
     if (a.sC != (size_t)a.M * a.ldc) return fail(RAFTCORR_EINVAL, "%s: C images must be contiguous", what);
-    const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit);
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, batch * ksplit);
     bool split16 = a.vecA && a.vecB;                         // unaligned operands: the fp32-MFMA kernel
 #if defined(RC_LAB)                    // tools/ only: force the fp32-MFMA kernel
     if (getenv("RC_BWD_FP32")) split16 = false;
@@ -631,7 +658,14 @@ static int run_gemm(GemmArgs a, int batch, float* partial, const char* what, hip
     bool f16 = a.maxA && a.maxB;
 #if defined(RC_LAB)                    // tools/ only: the three-piece bf16 kernel
     if (getenv("RC_BWD_BF16X3")) f16 = false;
+    if (getenv("RC_BWD_NOSKIP")) { a.kskip_from = INT_MAX; a.nremap_from = INT_MAX; }
 #endif
+    if (!split16) { a.kskip_from = INT_MAX; a.nremap_from = INT_MAX; }
+    if (a.scat_h && (!split16 || ksplit > 1)) return fail(RAFTCORR_EINVAL, "%s: scattered store needs the 16-bit kernel without K split", what);
+    if (!B_K_CONTIG && a.nremap_from != INT_MAX) {           // the paired tiles: half as many past nremap_from
+        const int tiles = (a.N + 127) / 128;
+        grid.x = a.nremap_from + (tiles - a.nremap_from + 1) / 2;
+    }
     if (split16 && f16)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<B_K_CONTIG, true>), grid, dim3(256), 0, s, a);
     else if (split16)
@@ -716,9 +750,7 @@ static int contract_stage(const float* f1, const float* f2, int B, int D, int H,
     const int N = H * W;
     const LevelGeom g0 = level_geom(H, W, 0);
     const size_t S0 = (size_t)g0.slab;
-    int rc = launch_maxabs(f1, f2, (size_t)B * D * N, maxima, s);
-    if (rc) return rc;
-    rc = launch_maxabs1(wgmax, n_wg, maxima + 256, s);
+    int rc = launch_maxabs3(f1, f2, (size_t)B * D * N, wgmax, n_wg, maxima, s);      // maxima[0..127], [128..255], [256..383]
     if (rc) return rc;
 
     float* f2v = (float*)workspace;                 // [B][D][S0]
@@ -730,6 +762,11 @@ static int contract_stage(const float* f1, const float* f2, int B, int D, int H,
     if (rc) return rc;
 
     GemmArgs a = {};
+    // bottom patch row with an all-padding lower half: dF1 skips those K blocks, dF2 pairs the upper halves
+    const bool low_pad = H % PATCH_H >= 1 && H % PATCH_H <= 4;
+    const int first_bottom = (patches_h(H) - 1) * patches_w(W);
+    a.kskip_from = low_pad ? first_bottom * PATCH_CELLS : INT_MAX;
+    a.nremap_from = low_pad ? first_bottom : INT_MAX;
     // dF1[d][q] = sum_p F2v[d][p] * dC0[q][p]      (B operand: k = p contiguous)
     a.A = f2v; a.B = d0; a.C = df1; a.M = D; a.N = N; a.K = (int)S0;
     a.lda = (int)S0; a.ldb = (int)S0; a.ldc = N;
@@ -742,6 +779,13 @@ static int contract_stage(const float* f1, const float* f2, int B, int D, int H,
     a.lda = N; a.ldb = (int)S0; a.ldc = (int)S0;
     a.sA = (size_t)D * N; a.sB = (size_t)N * S0; a.sC = (size_t)D * S0;
     a.maxA = maxima;
+    // one K range and 16-byte-aligned operands (the 16-bit kernel): the GEMM stores dF2 at its pixels itself
+    const bool aligned = N % 4 == 0 && ((uintptr_t)f1 | (uintptr_t)d0) % 16 == 0;
+    if (aligned && gemm_ksplit(a.M, a.N, a.K, B) == 1) {
+        a.C = df2; a.ldc = N; a.sC = (size_t)D * N;
+        a.scat_h = H; a.scat_w = W; a.scat_pw = patches_w(W);
+        return run_gemm<false>(a, B, planes, "gemm_bf16x3_kernel<dF2>", s);
+    }
     rc = run_gemm<false>(a, B, planes, "gemm_f32_kernel<dF2>", s);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_cols_scatter_back_kernel, dim3(grid_for((size_t)B * D * N, 16384)), dim3(256), 0, s,

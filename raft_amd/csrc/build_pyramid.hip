@@ -253,13 +253,23 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
         r2 = __builtin_amdgcn_make_buffer_rsrc(L > 2 ? base(2) : base(0), 0, L > 2 ? (int)(rows * p.slab[2] * ES) : 0, 0x00020000);
         r3 = __builtin_amdgcn_make_buffer_rsrc(L > 3 ? base(3) : base(0), 0, L > 3 ? (int)(rows * p.slab[3] * ES) : 0, 0x00020000);
     }
+#if defined(RC_LAB_TILE_MAJOR)       // tools/build_lab.hip only: level 0 stored as [query tile][patch][128 rows][128 cells]
+    r0 = __builtin_amdgcn_make_buffer_rsrc((char*)p.lvl[0] + ((((size_t)b * p.tilesM + m0 / BM) * p.tilesN + tn) * 128 + wave * 32) * 128 * ES,
+                                           0, (int)(rows * 128 * ES), 0x00020000);
+    const unsigned s0b = 128 * ES, s1b = (unsigned)(p.slab[1] * ES);
+#else
     const unsigned s0b = (unsigned)(p.slab[0] * ES), s1b = (unsigned)(p.slab[1] * ES);
+#endif
     const unsigned s2b = (unsigned)(p.slab[2] * ES), s3b = (unsigned)(p.slab[3] * ES);
     // Lane l31 holds cells 4*l31 .. 4*l31+3 of the patch (accumulator n = cell 4*l31 + n): one
     // even-aligned 2x2 block of level 0.  Bits of l31 (layout.h): a0 = dy1, a1 = dx1, a2 = dx2,
     // a3 = column half, a4 = row half of the patch.
     const int a0 = lane & 1, a1 = (lane >> 1) & 1, a2 = (lane >> 2) & 1, a3 = (lane >> 3) & 1, a4 = (lane >> 4) & 1;
+#if defined(RC_LAB_TILE_MAJOR)
+    const unsigned c0 = (unsigned)(4 * l31) * ES;
+#else
     const unsigned c0 = (unsigned)(tn * 128 + 4 * l31) * ES;
+#endif
     const unsigned c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * ES;
     const unsigned c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * ES;
     const int ph = tn / p.PW, pwi = tn - ph * p.PW;
@@ -437,10 +447,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // partial maxima of |x| of both feature maps: grid (MAXPARTS, 2), out[map * MAXPARTS + block]
 __global__ __launch_bounds__(256)
-void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ f2, size_t n, float* __restrict__ out)
+void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ f2, size_t n, float* __restrict__ out,
+                        const float* __restrict__ f3, size_t n3)
 {
     __shared__ float red[4];
-    const float* __restrict__ x = blockIdx.y ? f2 : f1;
+    const float* __restrict__ x = blockIdx.y == 2 ? f3 : blockIdx.y ? f2 : f1;
+    if (blockIdx.y == 2) n = n3;
     float m = 0.f;
     const size_t n4 = (((uintptr_t)x & 15) == 0) ? n >> 2 : 0;           // 16-byte loads when aligned
     constexpr size_t STRIDE = (size_t)MAXPARTS * 256;
@@ -469,14 +481,21 @@ void corr_maxabs_kernel(const float* __restrict__ f1, const float* __restrict__ 
 // partial maxima of two equally sized maps (out: [2][MAXPARTS]); also the range pass of the on-the-fly path's pack
 int launch_maxabs(const float* f1, const float* f2, size_t n, float* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, n, out);
+    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, n, out, (const float*)nullptr, (size_t)0);
+    return check_launch("corr_maxabs_kernel");
+}
+
+// two equally sized maps and a third array of its own length in one launch (out: [3][MAXPARTS])
+int launch_maxabs3(const float* f1, const float* f2, size_t n, const float* f3, size_t n3, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 3), dim3(256), 0, s, f1, f2, n, out, f3, n3);
     return check_launch("corr_maxabs_kernel");
 }
 
 // partial maxima of one array (out: [MAXPARTS]); the range pass of the on-the-fly backward's d(out)
 int launch_maxabs1(const float* x, size_t n, float* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 1), dim3(256), 0, s, x, x, n, out);
+    hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 1), dim3(256), 0, s, x, x, n, out, (const float*)nullptr, (size_t)0);
     return check_launch("corr_maxabs_kernel");
 }
 
@@ -721,7 +740,7 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
         const dim3 pgrid(a.tilesM + a.tilesN, PACK_KSPLIT, B);
         if (f16) {          // range pass: max|x| of both maps -> power-of-two scales (pack) and the unscale (epilogue)
             float* mp = (float*)((char*)workspace + build_workspace_bytes(B, D, H, W) - 2 * MAXPARTS * sizeof(float));
-            hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, (size_t)B * D * a.N, mp);
+            hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), dim3(256), 0, s, f1, f2, (size_t)B * D * a.N, mp, (const float*)nullptr, (size_t)0);
             rc = check_launch("corr_maxabs_kernel");
             if (rc) return rc;
             pk.maxpart = mp; a.maxpart = mp;

@@ -82,30 +82,42 @@ void corr_record_kernel(RecordArgs p)
     }
 }
 
-// The same transposition with ALL channels of 32 queries in one workgroup (C % 4 == 0, C <= 512): a thread loads four
+// The same transposition with ALL channels of QB queries in one workgroup (C % 4 == 0, C <= 512): a thread loads four
 // consecutive channels of its query and writes them to LDS as one 16-byte slot of the query's row (row pitch an odd
 // number of slots: the 16 rows a quarter-wave writes fall on different banks), and the workgroup's part of the record
-// -- 32 complete rows, 32 * C floats -- goes out as ONE contiguous run (41 KB at C = 324) instead of 432-byte pieces.
-// grid (ceil(N / 32), B), block 256, dynamic LDS 32 * (C / 4 | 1) * 16 bytes; IT: channel quads per thread (8 IT >= C / 4)
-template <int IT>
+// -- QB complete rows, QB * C floats -- goes out as ONE contiguous run (21 KB at C = 324, QB = 16) instead of 432-byte
+// pieces.  grid (ceil(N / QB), B), block 256, dynamic LDS QB * (C / 4 | 1) * 16 bytes; IT: channel quads per thread
+// (IT * 256 / QB >= C / 4)
+template <int IT, int QB>
 __global__ __launch_bounds__(256)
 void corr_record_rows_kernel(RecordArgs p)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 rows4[];   // [32][S4]
-    const int tid = threadIdx.x, q0 = blockIdx.x * 32, b = blockIdx.y;
-    const int C4 = p.C >> 2, S4 = C4 | 1, nq = min(32, p.N - q0);
-    const int qi = tid & 31, cg = tid >> 5;
+    extern __shared__ __attribute__((aligned(16))) float4 rows4[];   // [QB][S4]
+    // Workgroup ids go round-robin over the 8 XCDs; every XCD takes a contiguous run of (image, query block) instead: a
+    // channel's QB floats of a query block are part of a 128-byte line that the neighbouring block needs too.
+    int b, q0;
+    {
+        const int total = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = lin & 7, qd = total >> 3, rm = total & 7;
+        const int at = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);
+        b = at / gridDim.x;
+        q0 = (at - b * gridDim.x) * QB;
+    }
+    constexpr int CGS = 256 / QB;                                    // channel quads loaded side by side
+    const int tid = threadIdx.x;
+    const int C4 = p.C >> 2, S4 = C4 | 1, nq = min(QB, p.N - q0);
+    const int qi = tid & (QB - 1), cg = tid / QB;
     const float* __restrict__ src = p.dout + (size_t)b * p.C * p.N + q0 + min(qi, nq - 1);
     float4 v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {                                   // every load in flight before the first use
-        const int c = 4 * min(cg + 8 * i, C4 - 1);
+        const int c = 4 * min(cg + CGS * i, C4 - 1);
         v[i].x = src[(size_t)c * p.N]; v[i].y = src[(size_t)(c + 1) * p.N];
         v[i].z = src[(size_t)(c + 2) * p.N]; v[i].w = src[(size_t)(c + 3) * p.N];
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i)
-        if (cg + 8 * i < C4) rows4[qi * S4 + cg + 8 * i] = v[i];
+        if (cg + CGS * i < C4) rows4[qi * S4 + cg + CGS * i] = v[i];
     __syncthreads();
     float4* __restrict__ dst = (float4*)(p.rec + ((size_t)b * p.N + q0) * p.C);
     for (int e = tid; e < nq * C4; e += 256) {
@@ -411,13 +423,16 @@ int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec,
     a.dout = dout; a.rec = rec; a.N = N; a.C = C;
     if ((C & 3) == 0 && C <= 512 && ((uintptr_t)rec & 15) == 0) {     // whole rows per workgroup
         a.CH = C;
-        const int it = ((C >> 2) + 7) / 8;
-        const dim3 grid((N + 31) / 32, B);
-        const size_t lds = (size_t)32 * ((C >> 2) | 1) * 16;
-        if (it <= 4)       hipLaunchKernelGGL(corr_record_rows_kernel<4>, grid, dim3(256), lds, s, a);
-        else if (it <= 7)  hipLaunchKernelGGL(corr_record_rows_kernel<7>, grid, dim3(256), lds, s, a);     // r = 3, 4 levels
-        else if (it <= 11) hipLaunchKernelGGL(corr_record_rows_kernel<11>, grid, dim3(256), lds, s, a);    // r = 4, 4 levels
-        else               hipLaunchKernelGGL(corr_record_rows_kernel<16>, grid, dim3(256), lds, s, a);
+        // 16 queries per workgroup (21 KB of LDS at C = 324, 7 workgroups per CU): at Things B=6 the 1692 workgroups are
+        // resident together; with 32 queries (42 KB, 3 per CU) the launch was one round of 768 and a second of 78
+        constexpr int QB = 16;
+        const int it = ((C >> 2) + 15) / 16;
+        const dim3 grid((N + QB - 1) / QB, B);
+        const size_t lds = (size_t)QB * ((C >> 2) | 1) * 16;
+        if (it <= 2)      hipLaunchKernelGGL((corr_record_rows_kernel<2, QB>), grid, dim3(256), lds, s, a);
+        else if (it <= 4) hipLaunchKernelGGL((corr_record_rows_kernel<4, QB>), grid, dim3(256), lds, s, a);     // r = 3, 4 levels
+        else if (it <= 6) hipLaunchKernelGGL((corr_record_rows_kernel<6, QB>), grid, dim3(256), lds, s, a);     // r = 4, 4 levels
+        else              hipLaunchKernelGGL((corr_record_rows_kernel<8, QB>), grid, dim3(256), lds, s, a);
         return check_launch("corr_record_rows_kernel");
     }
     const int chunks = (C + 127) / 128;

@@ -67,6 +67,7 @@ int launch_alt_lookup_fwd16(const void* f1p, const void* const* f2p, const float
                             int r, const float* coords, float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t alt_lookup_fwd_sorted_workspace_bytes(int B, int H, int W, int L);
 int launch_maxabs1(const float* x, size_t n, float* out, hipStream_t s);
+int launch_maxabs3(const float* f1, const float* f2, size_t n, const float* f3, size_t n3, float* out, hipStream_t s);
 size_t alt_tiles_bytes(int B, int C, int H, int W);
 int launch_alt_pack_tiles(const float* fmap, int B, int C, int H, int W, const float* maxpart, void* packed, hipStream_t s);
 size_t alt_lookup_bwd_workspace_bytes(int B, int H, int W, int C, int L, int r, bool window = false, int nk = 1);

@@ -713,12 +713,15 @@ def test_all_pairs_backward_is_bit_reproducible(dev):
 
 
 @pytest.mark.parametrize("case", [(2, 32, 40, 72, 4, 4, 12), (1, 16, 13, 19, 2, 3, 3), (1, 24, 21, 34, 3, 5, 20),
-                                  (3, 8, 9, 21, 1, 4, 2), (1, 16, 24, 40, 4, 7, 11), (1, 8, 16, 24, 4, 0, 2)])
+                                  (3, 8, 9, 21, 1, 4, 2), (1, 16, 24, 40, 4, 7, 11), (1, 8, 16, 24, 4, 0, 2),
+                                  (2, 16, 12, 40, 3, 4, 3), (1, 8, 50, 90, 4, 4, 2), (1, 8, 18, 48, 2, 3, 2)])
 def test_deferred_backward_matches_accumulate_and_oracle(case, dev):
     """raftcorr_build_bwd_deferred (lookups recorded, one kernel makes the folded level-0 gradient in LDS) against
     raftcorr_lookup_bwd + raftcorr_build_bwd (dense gradient pyramid, folded once) and against the oracle's autograd:
     both coordinate conventions, odd sizes, every radius class (3, 4 specialised; 0, 5, 7 generic), more lookups than
-    one launch stages (16), coordinates outside the map; the same bits on a second run."""
+    one launch stages (16), coordinates outside the map; the same bits on a second run.  The last three shapes have a
+    bottom patch row whose lower half is padding only (H % 8 in 1..4) and 16-byte-aligned operands: the 16-bit gradient
+    GEMMs skip those K blocks and pair the upper halves of those patches (odd and even patch counts per row)."""
     from raft_amd import CorrBlock
     from oracle import corr_oracle as O
     B, D, H, W, L, r, nl = case

@@ -89,14 +89,14 @@ int main(int argc, char** argv)
     {   // 2 x fp16 operands (range scaling skipped: inputs are in [-1, 1]; maxpart = null -> unscale 1)
         pk.f2p = ws + (size_t)B * a.tilesM * D * 64 * 2; a.f1p = pk.f1p; a.f2p = pk.f2p;
         float* mp; CK(hipMalloc(&mp, 2 * MAXPARTS * 4));
-        hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp);
+        hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp, (const float*)nullptr, (size_t)0);
         pk.maxpart = mp; a.maxpart = mp;
         hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk);
         RUN("fp16x2 (2 pieces, 3 products)", corr_build_bf16_kernel<true, 2, true>);
         RUN("fp16x2 -> fp16 volume", corr_build_bf16_kernel<true, 2, true, 1>);
         printf("pack fp16x2: %.1f us, max|x| pass: %.1f us\n",
                timeit([&]() { hipLaunchKernelGGL((corr_pack_bf16_kernel<2, true>), pgrid, block, 0, 0, pk); }),
-               timeit([&]() { hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp); }));
+               timeit([&]() { hipLaunchKernelGGL(corr_maxabs_kernel, dim3(MAXPARTS, 2), block, 0, 0, f1, f2, (size_t)D * N, mp, (const float*)nullptr, (size_t)0); }));
     }
     return 0;
 }
