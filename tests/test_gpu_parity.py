@@ -49,9 +49,9 @@ def test_golden_forward_backward(name, dev):
 
 
 @pytest.mark.parametrize("shape", [(1, 256, 55, 128), (1, 256, 47, 156), (2, 128, 27, 64),
-                                   (1, 40, 13, 32), (3, 7, 9, 21), (1, 256, 50, 90)])
+                                   (1, 40, 13, 32), (3, 7, 9, 21), (1, 256, 50, 90), (2, 40, 32, 48), (2, 24, 30, 44)])
 def test_pyramid_matches_oracle(shape, dev):
-    """All-pairs build + fused pooled levels at the BASELINE shapes and odd sizes."""
+    """All-pairs build + fused pooled levels at the BASELINE shapes and odd sizes; the same bits on a second build."""
     from raft_amd import CorrBlock
     from oracle import corr_oracle as O
     B, D, H, W = shape
@@ -68,6 +68,9 @@ def test_pyramid_matches_oracle(shape, dev):
     c = CorrBlock.corr(f1.to(dev), f2.to(dev))
     assert c.shape == (B, H, W, 1, H, W)
     assert rel_err(c.cpu().numpy(), O.all_pairs_corr_torch(f1, f2).numpy()) <= TOL
+    again = CorrBlock(f1.to(dev), f2.to(dev), num_levels=L, radius=4)           # same bits on a second build
+    for l in range(L):
+        assert torch.equal(cb.corr_pyramid[l], again.corr_pyramid[l]), f"level {l} differs between two builds"
 
 
 def test_more_than_four_levels(dev):
