@@ -58,7 +58,19 @@ struct PackArgs {
     const float* f1; const float* f2; float* f1p; float* f2p;
     int D, Dpad, H, W, tilesM, tilesN;
     const float* maxpart;       // fp16 pieces only: MAXPARTS partial maxima of |fmap1|, then of |fmap2| (device memory)
+    int pair_from = 0x7fffffff; // F2 panels >= this hold the upper halves (cells 0..63) of TWO patches, see paired_cell()
 };
+
+// Paired panels.  With H % 8 in 1..4 the lower 4x16 half of every patch of the bottom patch row is padding only (cells
+// 64..127, layout.h); one panel then carries the upper halves of two such patches -- cells 0..63 of patch
+// pair_from + 2 (panel - pair_from) in its columns 0..63, of the next patch in columns 64..127 -- and the bottom row
+// costs half the tiles (50x90: 39 panels instead of 42).  The main loops do not know; the pack kernels gather the
+// columns and the epilogue addresses the stores accordingly.  cell m of panel `tile` -> (patch, cell inside the patch)
+__device__ __forceinline__ void paired_cell(int pair_from, int tile, int m, int& patch, int& cell)
+{
+    patch = tile; cell = m;
+    if (tile >= pair_from) { patch = pair_from + 2 * (tile - pair_from) + (m >> 6); cell = m & 63; }
+}
 
 __global__ __launch_bounds__(256)
 void corr_pack_kernel(PackArgs p)
@@ -75,12 +87,14 @@ void corr_pack_kernel(PackArgs p)
     } else {
         tile -= p.tilesM;
         const int PW = patches_w(p.W);
-        const int n = c >> 5, j = c & 31;                 // column c = cell c of the patch: tile n, position j
+        int patch, cell;
+        paired_cell(p.pair_from, tile, c, patch, cell);   // column c = cell c of the panel
+        const int n = cell >> 5, j = cell & 31;           // tile n of the patch, position j
         const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
         const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
-        const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
-        const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
-        if (y < p.H && x < p.W) t = y * p.W + x;
+        const int y = (patch / PW) * PATCH_H + (n >> 1) * 4 + dy;
+        const int x = (patch % PW) * PATCH_W + (n & 1) * 8 + dx;
+        if (y < p.H && x < p.W) t = y * p.W + x;          // (an odd patch out: y >= H)
     }
     const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
     float* __restrict__ dst = (second ? p.f2p + ((size_t)b * p.tilesN + tile) * p.Dpad * 128
@@ -103,9 +117,9 @@ void corr_pack_kernel(PackArgs p)
 }
 
 int launch_pack_operands(const float* f1, const float* f2, float* f1p, float* f2p, int B, int D, int Dpad,
-                         int H, int W, int tilesM, int tilesN, hipStream_t s)
+                         int H, int W, int tilesM, int tilesN, hipStream_t s, int pair_from = 0x7fffffff)
 {
-    PackArgs a{f1, f2, f1p, f2p, D, Dpad, H, W, tilesM, tilesN, nullptr};
+    PackArgs a{f1, f2, f1p, f2p, D, Dpad, H, W, tilesM, tilesN, nullptr, pair_from};
     hipLaunchKernelGGL(corr_pack_kernel, dim3(tilesM + tilesN, PACK_KSPLIT, B), dim3(256), 0, s, a);
     return check_launch("corr_pack_kernel");
 }
@@ -124,6 +138,8 @@ struct BuildArgs {
     float inv_sqrt_d;     // used when sqrt(D) is a power of two (exact)
     float sqrt_d;         // divisor otherwise (bit-faithful to corr / sqrt(D), corr.py:61)
     const float* maxpart;     // fp16 pieces only (else null): the operands were scaled, see range_exponent()
+    int pair_from = 0x7fffffff;   // panels (tn) >= this are paired (paired_cell()); tilesN counts panels
+    int npatch = 0;               // patches of the target map (an odd patch out has no partner)
 };
 
 constexpr int MAXPARTS = 128;    // partial maxima per feature map (one per block of corr_maxabs_kernel)
@@ -265,15 +281,29 @@ __device__ __forceinline__ void build_epilogue(const BuildArgs& p, f32x16 (&acc)
     // even-aligned 2x2 block of level 0.  Bits of l31 (layout.h): a0 = dy1, a1 = dx1, a2 = dx2,
     // a3 = column half, a4 = row half of the patch.
     const int a0 = lane & 1, a1 = (lane >> 1) & 1, a2 = (lane >> 2) & 1, a3 = (lane >> 3) & 1, a4 = (lane >> 4) & 1;
+    unsigned c0, c1, c2, c3;
+    if (tn < p.pair_from) {                                  // (workgroup-uniform)
 #if defined(RC_LAB_TILE_MAJOR)
-    const unsigned c0 = (unsigned)(4 * l31) * ES;
+        c0 = (unsigned)(4 * l31) * ES;
 #else
-    const unsigned c0 = (unsigned)(tn * 128 + 4 * l31) * ES;
+        c0 = (unsigned)(tn * 128 + 4 * l31) * ES;
 #endif
-    const unsigned c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * ES;
-    const unsigned c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * ES;
-    const int ph = tn / p.PW, pwi = tn - ph * p.PW;
-    const unsigned c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * ES;
+        c1 = (unsigned)(tn * 32 + (l31 >> 3) * 8 + (a1 | (a0 << 1) | (a2 << 2))) * ES;
+        c2 = (unsigned)(tn * 8 + (a2 | (a4 << 1) | (a3 << 2))) * ES;
+        const int ph = tn / p.PW, pwi = tn - ph * p.PW;
+        c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * ES;
+    } else {
+        // paired panel: MFMA columns 0..15 are the upper half of one patch, 16..31 of the next (a4 picks the patch; both
+        // sit in the upper row half).  The pooled values that reach across a4 -- level 3, and nothing else -- belong to
+        // cells below the level's last row (H % 8 <= 4) and land in those cells' own slots; an odd patch out stores nothing.
+        const int patch = p.pair_from + 2 * (tn - p.pair_from) + a4, l15 = l31 & 15;
+        const int ph = patch / p.PW, pwi = patch - ph * p.PW;
+        c0 = (unsigned)(patch * 128 + 4 * l15) * ES;
+        c1 = (unsigned)(patch * 32 + a3 * 8 + (a1 | (a0 << 1) | (a2 << 2))) * ES;
+        c2 = (unsigned)(patch * 8 + (a2 | (a3 << 2))) * ES;
+        c3 = (unsigned)(((ph >> 1) * p.PW + pwi) * 4 + a3 + (ph & 1) * 2) * ES;
+        if (patch >= p.npatch) c0 = c1 = c2 = c3 = 0x80000000u;            // beyond every descriptor: dropped
+    }
     const int quad = lane & 3;
     const unsigned rowk = 4 * kh;
 
@@ -525,11 +555,13 @@ void corr_pack_bf16_kernel(PackArgs p)
         tile -= p.tilesM;
         const int PW = patches_w(p.W);
         const int m = (c & 31) * 4 + (c >> 5);            // slot = accumulator*32 + MFMA column <-> cell 4*column + accumulator
-        const int n = m >> 5, j = m & 31;
+        int patch, cell;
+        paired_cell(p.pair_from, tile, m, patch, cell);
+        const int n = cell >> 5, j = cell & 31;
         const int dx = (j & 1) | (((j >> 3) & 1) << 1) | ((j >> 4) << 2);
         const int dy = ((j >> 1) & 1) | (((j >> 2) & 1) << 1);
-        const int y = (tile / PW) * PATCH_H + (n >> 1) * 4 + dy;
-        const int x = (tile % PW) * PATCH_W + (n & 1) * 8 + dx;
+        const int y = (patch / PW) * PATCH_H + (n >> 1) * 4 + dy;
+        const int x = (patch % PW) * PATCH_W + (n & 1) * 8 + dx;
         if (y < p.H && x < p.W) t = y * p.W + x;
     }
     const float* __restrict__ src = (second ? p.f2 : p.f1) + (size_t)b * p.D * N + (t >= 0 ? t : 0);
@@ -721,8 +753,16 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     a.B = B; a.N = H * W; a.L = L < 4 ? L : 4;
     a.Dpad = (D + 63) / 64 * 64;             // multiple of every K tile and of the pack kernels' k split
     a.tilesM = (a.N + BM - 1) / BM;
-    a.tilesN = patches_h(H) * patches_w(W);
+    a.npatch = patches_h(H) * patches_w(W);
+    a.tilesN = a.npatch;
     a.PW = patches_w(W);
+    if (H % PATCH_H >= 1 && H % PATCH_H <= 4) {              // bottom patch row: two upper halves per panel (paired_cell())
+        a.pair_from = (patches_h(H) - 1) * a.PW;
+        a.tilesN = a.pair_from + (a.PW + 1) / 2;
+    }
+#if defined(RC_LAB)                    // tools/ only
+    if (getenv("RC_NO_PAIRS")) { a.pair_from = 0x7fffffff; a.tilesN = a.npatch; }
+#endif
     // bf16 on volumes far beyond the 256 MB infinity cache is bound by HBM write efficiency: one
     // query tile at a time per XCD keeps each row's concurrently written segment long (measured at
     // 1080p: 1.61 ms vs 2.35 ms with groups of 8; at Sintel size the grouping of 8 is the faster one)
@@ -736,7 +776,7 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
     int rc;
     a.maxpart = nullptr;
     if (bf16) {
-        PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN, nullptr};
+        PackArgs pk{f1, f2, f1p, f2p, D, a.Dpad, H, W, a.tilesM, a.tilesN, nullptr, a.pair_from};
         const dim3 pgrid(a.tilesM + a.tilesN, PACK_KSPLIT, B);
         if (f16) {          // range pass: max|x| of both maps -> power-of-two scales (pack) and the unscale (epilogue)
             float* mp = (float*)((char*)workspace + build_workspace_bytes(B, D, H, W) - 2 * MAXPARTS * sizeof(float));
@@ -749,7 +789,7 @@ int launch_build_pyramid(const float* f1, const float* f2, int B, int D, int H, 
         else                hipLaunchKernelGGL((corr_pack_bf16_kernel<1, false>), pgrid, dim3(256), 0, s, pk);
         rc = check_launch("corr_pack_bf16_kernel");
     } else {
-        rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s);
+        rc = launch_pack_operands(f1, f2, f1p, f2p, B, D, a.Dpad, H, W, a.tilesM, a.tilesN, s, a.pair_from);
     }
     if (rc) return rc;
     a.f1p = f1p; a.f2p = f2p;
