@@ -267,16 +267,21 @@ void alt_wscan_kernel(WSortArgs p)
 // The same groups in ONE launch for maps of up to WS_MAXQ queries (every BASELINE shape but 1080p): one workgroup per
 // batch item keeps the whole count table in LDS -- cnt[chunk of 64 queries][bucket], 16 bits each -- so the three
 // passes above become three phases between barriers and two of the three launch latencies (5 us each at this size)
-// go away.  A wave owns every 16th chunk; inside a chunk the queries of one bucket are found by ballots over the
-// chunk's distinct keys, which gives the per-chunk counts and each query's rank among its chunk mates of that
-// bucket; the exclusive prefix over the chunks of a bucket, the rows of cells laid end to end and the row-end padding
-// are those of alt_wscan_kernel / alt_wbucket_kernel<true>: the lists are the same, bit for bit.
+// go away.  A wave owns WS_MAXC consecutive chunks; inside a chunk the queries of one bucket find each other through a
+// lane mask per bucket, which gives the per-chunk counts and each query's rank among its chunk mates of that bucket.
+// The wave walks its chunks in order and keeps a running count per bucket (its own row of `run`), so what it leaves in
+// cnt is already the exclusive prefix over ITS chunks; the prefix over all chunks of a bucket is then a scan over the 16
+// waves' totals (16 table reads per bucket; the first version scanned the 115 chunks of a bucket with one thread:
+// 3.7 of the launch's 11.5 us at KITTI size, and had to clear the whole count table first).  The rows of cells laid
+// end to end and the row-end padding are those of alt_wscan_kernel / alt_wbucket_kernel<true>: the lists are the same,
+// bit for bit.
 // grid (B), block 1024, dynamic LDS = ws_small_lds(nch64, nb, nby)
 constexpr int WS_WAVES = 16, WS_MAXC = 8, WS_MAXQ = WS_WAVES * WS_MAXC * 64;
 
 __host__ __device__ inline size_t ws_small_lds(int nch64, int nb, int nby)
 {
-    return (((size_t)nch64 * nb * 2 + 15) & ~(size_t)15) + 8 * (size_t)WS_WAVES * nb + sizeof(int) * (2 * (size_t)nb + 2 * (size_t)nby);
+    return (((size_t)nch64 * nb * 2 + 15) & ~(size_t)15) + (8 + sizeof(int)) * (size_t)WS_WAVES * nb +
+           sizeof(int) * (2 * (size_t)nb + 2 * (size_t)nby);
 }
 
 // exclusive prefix of v over the lanes of a wave; total = the sum over all 64 lanes
@@ -296,9 +301,10 @@ void alt_wgroups_small_kernel(WSortArgs p)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nch64 = (p.N + 63) >> 6, nb = p.nb;
-    unsigned short* __restrict__ cnt = (unsigned short*)wsm;                               // [nch64][nb]
+    unsigned short* __restrict__ cnt = (unsigned short*)wsm;                               // [nch64][nb], written where read
     unsigned long long* masks = (unsigned long long*)(wsm + (((size_t)nch64 * nb * 2 + 15) & ~(size_t)15));   // [16 waves][nb]
-    int* __restrict__ tot = (int*)(masks + (size_t)WS_WAVES * nb);                         // [nb] queries of the bucket
+    int* __restrict__ run = (int*)(masks + (size_t)WS_WAVES * nb);                         // [16 waves][nb] running counts
+    int* __restrict__ tot = run + (size_t)WS_WAVES * nb;                                   // [nb] queries of the bucket
     int* __restrict__ toffs = tot + nb;                                                    // [nb] first slot of the bucket
     int* __restrict__ rowg = toffs + nb;                                                   // [nby] first group of the row
     int* __restrict__ rowlen = rowg + p.nby;                                               // [nby] queries of the row
@@ -307,11 +313,10 @@ void alt_wgroups_small_kernel(WSortArgs p)
     float x[WS_MAXC], y[WS_MAXC];
 #pragma unroll
     for (int u = 0; u < WS_MAXC; ++u) {                       // all loads of the wave in flight
-        const int q = min((wave + WS_WAVES * u) * 64 + lane, p.N - 1);
+        const int q = min((wave * WS_MAXC + u) * 64 + lane, p.N - 1);
         x[u] = cx[q]; y[u] = cx[p.N + q];
     }
-    for (int i = tid; i < (nch64 * nb + 1) / 2; i += 1024) ((unsigned*)cnt)[i] = 0u;
-    for (int i = tid; i < WS_WAVES * nb; i += 1024) masks[i] = 0ull;
+    for (int i = tid; i < WS_WAVES * nb; i += 1024) { masks[i] = 0ull; run[i] = 0; }
     __syncthreads();
 
     // phase 1: per-chunk counts and ranks.  The lanes of a chunk that share a bucket find each other through a 64-bit
@@ -319,9 +324,10 @@ void alt_wgroups_small_kernel(WSortArgs p)
     // rank = set bits below the lane, count = all set bits; every lane clears the entry it used.
     int key[WS_MAXC], rank[WS_MAXC];
     unsigned long long* __restrict__ mask = masks + (size_t)wave * nb;
+    int* __restrict__ myrun = run + (size_t)wave * nb;
 #pragma unroll
     for (int u = 0; u < WS_MAXC; ++u) {
-        const int chunk = wave + WS_WAVES * u, q = chunk * 64 + lane;
+        const int chunk = wave * WS_MAXC + u, q = chunk * 64 + lane;
         const bool valid = q < p.N;
         key[u] = valid ? wbucket_key(p, x[u], y[u]) : 0;
         rank[u] = 0;
@@ -330,25 +336,26 @@ void alt_wgroups_small_kernel(WSortArgs p)
         if (valid) {
             const unsigned long long m = mask[key[u]];
             rank[u] = __popcll(m & ((1ull << lane) - 1));
-            if (rank[u] == 0) cnt[chunk * nb + key[u]] = (unsigned short)__popcll(m);
+            if (rank[u] == 0) {                                  // one lane per bucket of the chunk
+                const int before = myrun[key[u]];                // the bucket's queries in this wave's earlier chunks
+                cnt[chunk * nb + key[u]] = (unsigned short)before;
+                myrun[key[u]] = before + __popcll(m);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (valid) mask[key[u]] = 0ull;
     }
     __syncthreads();
 
-    // phase 2: exclusive prefix over the chunks of a bucket (eight table reads in flight per thread) ...
+    // phase 2: exclusive prefix over the waves' totals of a bucket (all 16 reads in flight) ...
     for (int k = tid; k < nb; k += 1024) {
-        int run = 0;
-        for (int c0 = 0; c0 < nch64; c0 += 8) {
-            int v[8];
+        int v[WS_WAVES];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = cnt[min(c0 + j, nch64 - 1) * nb + k];
+        for (int w = 0; w < WS_WAVES; ++w) v[w] = run[w * nb + k];
+        int acc = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (c0 + j < nch64) { cnt[(c0 + j) * nb + k] = (unsigned short)run; run += v[j]; }
-        }
-        tot[k] = run;
+        for (int w = 0; w < WS_WAVES; ++w) { run[w * nb + k] = acc; acc += v[w]; }
+        tot[k] = acc;
     }
     __syncthreads();
     // ... the buckets of a row of cells end to end (one wave per row) ...
@@ -382,10 +389,10 @@ void alt_wgroups_small_kernel(WSortArgs p)
     int* __restrict__ ql = p.qlist + (size_t)b * p.gmax * 64;
 #pragma unroll
     for (int u = 0; u < WS_MAXC; ++u) {
-        const int chunk = wave + WS_WAVES * u, q = chunk * 64 + lane;
+        const int chunk = wave * WS_MAXC + u, q = chunk * 64 + lane;
         if (q < p.N) {
             const int k = key[u];
-            ql[rowg[k / p.nbx] * 64 + toffs[k] + cnt[chunk * nb + k] + rank[u]] = q;
+            ql[rowg[k / p.nbx] * 64 + toffs[k] + myrun[k] + cnt[chunk * nb + k] + rank[u]] = q;
         }
     }
     for (int r = wave; r < p.nby; r += WS_WAVES) {
