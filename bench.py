@@ -341,7 +341,7 @@ class ThingsTrain(Workload):
     def kernels(self, phases_us):
         w = work_of(self.cfg)
         k = {"fwd": {"kernel": "corr_pack + corr_build_f32 + 12 x corr_lookup_fwd", "us": phases_us[0]},
-             "bwd": {"kernel": "12 x corr_record + corr_splat_fold + 2 GEMMs (+ all-reduce when N > 1, overlapped)", "us": phases_us[1]}}
+             "bwd": {"kernel": "corr_record (12 lookups, one launch) + corr_splat_fold + 2 GEMMs (+ all-reduce when N > 1, overlapped)", "us": phases_us[1]}}
         k["fwd"].update(frac_entry(k["fwd"]["kernel"], phases_us[0], "mfma", w["build_flops"], MFMA_F32_PEAK_TFLOPS,
                                    "TFLOP/s"))
         k["bwd"].update(mfma16_entry(k["bwd"]["kernel"], phases_us[1], 2 * w["gemm_flops"], 3,

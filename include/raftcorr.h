@@ -197,6 +197,10 @@ int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int
  *   raftcorr_lookup_bwd_record   canonical-mode d(out) (B, channels, H, W) -> record (B, H*W, channels), the layout the
  *                         fold reads (a query's channels contiguous); channels = L*rd*rd.  Fork-mode d(out)
  *                         (B, N, channels) IS a record already.
+ *   raftcorr_lookup_bwd_record_many  the same for n_lookups gradients in one call (douts / records: HOST arrays of
+ *                         DEVICE pointers): one launch per 16 lookups, whose rounds of workgroups overlap -- for a
+ *                         caller that keeps the d(out) tensors until the build node runs (12 lookups at Things B=6:
+ *                         one launch instead of 12 x 18 us).  Same bits as n_lookups single calls.
  *   raftcorr_build_bwd_deferred  coords / records: HOST arrays of n_lookups DEVICE pointers (coords as given to the
  *                         lookup: (B,N,2) fork, (B,2,H,W) canonical; any order: the sum runs in array order, the same
  *                         bits on every run).  dlevels: NULL, or a dense pyramid gradient as raftcorr_build_bwd takes it
@@ -209,6 +213,8 @@ int raftcorr_build_bwd(const float* fmap1, const float* fmap2, int B, int D, int
 int64_t raftcorr_build_bwd_deferred_workspace_bytes(int B, int D, int H, int W);
 int raftcorr_build_bwd_deferred_supported(int H, int W, int num_levels, int radius);
 int raftcorr_lookup_bwd_record(const float* dout, int B, int H, int W, int channels, float* record, void* stream);
+int raftcorr_lookup_bwd_record_many(const float* const* douts, int n_lookups, int B, int H, int W, int channels,
+                                    float* const* records, void* stream);
 int raftcorr_build_bwd_deferred(const float* fmap1, const float* fmap2, int B, int D, int H, int W, int num_levels,
                                 int radius, int mode, int n_lookups, const float* const* coords,
                                 const float* const* records, float* const* dlevels, float* dfmap1, float* dfmap2,

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "raftcorr_build_bwd_deferred_workspace_bytes": ([_c_int] * 4, ctypes.c_int64),
     "raftcorr_build_bwd_deferred_supported": ([_c_int] * 4, _c_int),
     "raftcorr_lookup_bwd_record": ([_c_fp] + [_c_int] * 4 + [_c_fp, ctypes.c_void_p], _c_int),
+    "raftcorr_lookup_bwd_record_many": ([ctypes.POINTER(ctypes.c_void_p)] + [_c_int] * 5 +
+                                        [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p], _c_int),
     "raftcorr_build_bwd_deferred": ([_c_fp, _c_fp] + [_c_int] * 8 + [ctypes.POINTER(ctypes.c_void_p)] * 3 +
                                     [_c_fp, _c_fp, _c_fp, ctypes.c_int64, ctypes.c_void_p], _c_int),
     "raftcorr_alt_forward": ([_c_fp, _c_fp, _c_fp, _c_fp] + [_c_int] * 8 + [ctypes.c_void_p], _c_int),

@@ -119,7 +119,7 @@ class _Pyramid:
         # the build node turns all of them into the folded level-0 gradient in one kernel.  Shapes it does not take
         # (more than 4 levels, very large maps) keep the accumulate-then-fold route.
         self.deferred = False
-        self.records = []         # [(mode, radius, coords, record (B, N, C))] of the running backward pass
+        self.records = []         # [(mode, radius, coords, record (B, N, C) | None, pending d(out) | None)] of the running backward pass
         self.rtask = None
 
     def out_shape(self, radius, mode):
@@ -181,14 +181,15 @@ class _Pyramid:
     def set_deferred(self, radius):
         self.deferred = bool(_lib.load().raftcorr_build_bwd_deferred_supported(self.H, self.W, self.L, radius))
 
-    def add_record(self, mode, radius, coords, rec):
+    def add_record(self, mode, radius, coords, rec, pending=None):
         """A lookup's (coords, d(out) as (B, N, C)) for the backward pass that is running now; what an earlier pass
-        left behind without reaching the build node is dropped (cf. grad_buffer)."""
+        left behind without reaching the build node is dropped (cf. grad_buffer).  pending: a canonical d(out)
+        (B, C, H, W) that is still to be transposed (rec is None): the build node does that for all lookups at once."""
         task = _graph_task_id()
         if self.rtask != task:
             self.records = []
         self.rtask = task
-        self.records.append((mode, radius, coords, rec))
+        self.records.append((mode, radius, coords, rec, pending))
 
     def records_take(self, mode):
         """One deferred launch serves one coordinate convention: a block that is looked up in both conventions inside
@@ -239,11 +240,29 @@ def _record(pyr, mode, radius, coords, dout, rows=None):
     elif mode == _lib.MODE_FORK:
         rec = dout
     else:
-        B, C = dout.shape[:2]
-        rec = torch.empty(B, pyr.N, C, dtype=torch.float32, device=dout.device)
-        _lib.check(_lib.load().raftcorr_lookup_bwd_record(dout.data_ptr(), B, pyr.H, pyr.W, C, rec.data_ptr(), _stream(dout)),
-                   "lookup_bwd_record")
+        # kept as it is: the build node transposes the d(out) of all lookups with one raftcorr_lookup_bwd_record_many
+        # (a launch per lookup is one round of workgroups that first all read, then all write; the rounds of one launch
+        # for all lookups overlap: 12 x 18 us -> ~ 150 us at Things B=6)
+        pyr.add_record(mode, radius, coords, None, dout)
+        return
     pyr.add_record(mode, radius, coords, rec)
+
+
+def _transpose_pending(pyr, recs, like):
+    """records with a pending canonical d(out) -> (B, N, C) rows, all of them in one library call."""
+    todo = [i for i, r in enumerate(recs) if r[3] is None]
+    if not todo:
+        return recs
+    B, C = recs[todo[0]][4].shape[:2]
+    rows = torch.empty(len(todo), B, pyr.N, C, dtype=torch.float32, device=like.device)
+    dptr = _lib.ptr_array([recs[i][4] for i in todo])
+    rptr = _lib.ptr_array([rows[j] for j in range(len(todo))])
+    _lib.check(_lib.load().raftcorr_lookup_bwd_record_many(dptr, len(todo), B, pyr.H, pyr.W, C, rptr, _stream(like)),
+               "lookup_bwd_record_many")
+    recs = list(recs)
+    for j, i in enumerate(todo):
+        recs[i] = recs[i][:3] + (rows[j], None)
+    return recs
 
 
 class _BuildPyramid(torch.autograd.Function):
@@ -285,9 +304,10 @@ class _BuildPyramid(torch.autograd.Function):
             wbytes = lib.raftcorr_build_bwd_workspace_bytes(B, D, H, W) if dense else \
                 lib.raftcorr_build_bwd_deferred_workspace_bytes(B, D, H, W)
             work = torch.empty(wbytes, dtype=torch.uint8, device=fmap1.device)
-            cptrs = _lib.ptr_array([r[2] for r in recs])
-            rptrs = _lib.ptr_array([r[3] for r in recs])
             with _guard(fmap1):
+                recs = _transpose_pending(pyr, recs, fmap1)
+                cptrs = _lib.ptr_array([r[2] for r in recs])
+                rptrs = _lib.ptr_array([r[3] for r in recs])
                 _lib.check(lib.raftcorr_build_bwd_deferred(fmap1.data_ptr(), fmap2.data_ptr(), B, D, H, W, pyr.L, radius, mode,
                                                            len(recs), cptrs, rptrs, pyr.dptrs if dense else None,
                                                            d1.data_ptr(), d2.data_ptr(), work.data_ptr(), wbytes,

@@ -282,6 +282,19 @@ int raftcorr_lookup_bwd_record(const float* dout, int B, int H, int W, int chann
     return launch_lookup_bwd_record(dout, B, H * W, channels, record, (hipStream_t)stream);
 }
 
+int raftcorr_lookup_bwd_record_many(const float* const* douts, int n_lookups, int B, int H, int W, int channels,
+                                    float* const* records, void* stream)
+{
+    int rc = check_dims("lookup_bwd_record_many", B, H, W);
+    if (rc) return rc;
+    if (n_lookups < 1 || n_lookups > 4096) return fail(RAFTCORR_EINVAL, "lookup_bwd_record_many: %d lookups", n_lookups);
+    if (!douts || !records) return fail(RAFTCORR_EINVAL, "lookup_bwd_record_many: null pointer");
+    if (channels < 1 || channels > 65535 * 256) return fail(RAFTCORR_EINVAL, "lookup_bwd_record_many: channels = %d", channels);
+    for (int k = 0; k < n_lookups; ++k)
+        if (!douts[k] || !records[k]) return fail(RAFTCORR_EINVAL, "lookup_bwd_record_many: lookup %d: null pointer", k);
+    return launch_lookup_bwd_record_many(douts, n_lookups, B, H * W, channels, records, (hipStream_t)stream);
+}
+
 int raftcorr_build_bwd_deferred(const float* fmap1, const float* fmap2, int B, int D, int H, int W, int num_levels,
                                 int radius, int mode, int n_lookups, const float* const* coords,
                                 const float* const* records, float* const* dlevels, float* dfmap1, float* dfmap2,

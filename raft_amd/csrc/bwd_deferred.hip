@@ -38,10 +38,13 @@ constexpr int DEF_STAGE_FLOATS = 6144;       // staging capacity (K * C floats p
 constexpr int DEF_MAX_LDS = 150 * 1024;
 constexpr unsigned DEF_MAX_GRID = 32768;     // = FOLD_MAX_GRID of build_bwd.hip (per-workgroup maxima)
 
+constexpr int REC_MAXK = 16;  // lookups per launch of corr_record_rows_kernel (blockIdx.z)
 struct RecordArgs {
     const float* dout;   // (B, C, N)
     float* rec;          // (B, N, C)
     int N, C, CH;        // CH: channels per tile
+    const float* douts[REC_MAXK];    // corr_record_rows_kernel: lookup blockIdx.z
+    float* recs[REC_MAXK];
 };
 
 // grid (ceil(N / 32), ceil(C / CH), B), block 256, LDS CH * 33 floats; CH <= 128: every load of a thread is in flight
@@ -107,7 +110,7 @@ void corr_record_rows_kernel(RecordArgs p)
     const int tid = threadIdx.x;
     const int C4 = p.C >> 2, S4 = C4 | 1, nq = min(QB, p.N - q0);
     const int qi = tid & (QB - 1), cg = tid / QB;
-    const float* __restrict__ src = p.dout + (size_t)b * p.C * p.N + q0 + min(qi, nq - 1);
+    const float* __restrict__ src = p.douts[blockIdx.z] + (size_t)b * p.C * p.N + q0 + min(qi, nq - 1);
     float4 v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {                                   // every load in flight before the first use
@@ -119,7 +122,7 @@ void corr_record_rows_kernel(RecordArgs p)
     for (int i = 0; i < IT; ++i)
         if (cg + CGS * i < C4) rows4[qi * S4 + cg + CGS * i] = v[i];
     __syncthreads();
-    float4* __restrict__ dst = (float4*)(p.rec + ((size_t)b * p.N + q0) * p.C);
+    float4* __restrict__ dst = (float4*)(p.recs[blockIdx.z] + ((size_t)b * p.N + q0) * p.C);
     for (int e = tid; e < nq * C4; e += 256) {
         const int q = e / C4, c4 = e - q * C4;
         dst[e] = rows4[q * S4 + c4];
@@ -417,29 +420,50 @@ DeferredPlan deferred_plan(int H, int W, int L, int r)
 
 bool build_bwd_deferred_supported(int H, int W, int L, int r) { return deferred_plan(H, W, L, r).ok; }
 
-int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec, hipStream_t s)
+// K transpositions (B, C, N) -> (B, N, C).  With whole rows per workgroup they are ONE launch per 16 lookups: a single
+// lookup's launch is one round of resident workgroups that first all read and then all write (18 us for 70 MB at
+// Things B=6, launch latency included); twelve lookups in one launch are twelve rounds that overlap.
+int launch_lookup_bwd_record_many(const float* const* douts, int K, int B, int N, int C, float* const* recs, hipStream_t s)
 {
-    RecordArgs a;
-    a.dout = dout; a.rec = rec; a.N = N; a.C = C;
-    if ((C & 3) == 0 && C <= 512 && ((uintptr_t)rec & 15) == 0) {     // whole rows per workgroup
-        a.CH = C;
-        // 16 queries per workgroup (21 KB of LDS at C = 324, 7 workgroups per CU): at Things B=6 the 1692 workgroups are
-        // resident together; with 32 queries (42 KB, 3 per CU) the launch was one round of 768 and a second of 78
+    bool rows = (C & 3) == 0 && C <= 512;
+    for (int k = 0; k < K; ++k) rows = rows && ((uintptr_t)recs[k] & 15) == 0;
+    if (rows) {                                                      // whole rows per workgroup
+        // 16 queries per workgroup (21 KB of LDS at C = 324, 7 workgroups per CU): at Things B=6 the 1692 workgroups of
+        // a lookup are resident together; with 32 queries (42 KB, 3 per CU) a launch was one round of 768 and one of 78
         constexpr int QB = 16;
         const int it = ((C >> 2) + 15) / 16;
-        const dim3 grid((N + QB - 1) / QB, B);
         const size_t lds = (size_t)QB * ((C >> 2) | 1) * 16;
-        if (it <= 2)      hipLaunchKernelGGL((corr_record_rows_kernel<2, QB>), grid, dim3(256), lds, s, a);
-        else if (it <= 4) hipLaunchKernelGGL((corr_record_rows_kernel<4, QB>), grid, dim3(256), lds, s, a);     // r = 3, 4 levels
-        else if (it <= 6) hipLaunchKernelGGL((corr_record_rows_kernel<6, QB>), grid, dim3(256), lds, s, a);     // r = 4, 4 levels
-        else              hipLaunchKernelGGL((corr_record_rows_kernel<8, QB>), grid, dim3(256), lds, s, a);
-        return check_launch("corr_record_rows_kernel");
+        for (int k0 = 0; k0 < K; k0 += REC_MAXK) {
+            const int kn = std::min(REC_MAXK, K - k0);
+            RecordArgs a = {};
+            a.N = N; a.C = C; a.CH = C;
+            for (int k = 0; k < kn; ++k) { a.douts[k] = douts[k0 + k]; a.recs[k] = recs[k0 + k]; }
+            const dim3 grid((N + QB - 1) / QB, B, kn);
+            if (it <= 2)      hipLaunchKernelGGL((corr_record_rows_kernel<2, QB>), grid, dim3(256), lds, s, a);
+            else if (it <= 4) hipLaunchKernelGGL((corr_record_rows_kernel<4, QB>), grid, dim3(256), lds, s, a);     // r = 3, 4 levels
+            else if (it <= 6) hipLaunchKernelGGL((corr_record_rows_kernel<6, QB>), grid, dim3(256), lds, s, a);     // r = 4, 4 levels
+            else              hipLaunchKernelGGL((corr_record_rows_kernel<8, QB>), grid, dim3(256), lds, s, a);
+            const int rc = check_launch("corr_record_rows_kernel");
+            if (rc) return rc;
+        }
+        return RAFTCORR_OK;
     }
-    const int chunks = (C + 127) / 128;
-    a.CH = std::min(128, ((C + chunks - 1) / chunks + 3) & ~3);
-    const dim3 grid((N + 31) / 32, (C + a.CH - 1) / a.CH, B);
-    hipLaunchKernelGGL(corr_record_kernel, grid, dim3(256), (size_t)a.CH * 33 * sizeof(float), s, a);
-    return check_launch("corr_record_kernel");
+    for (int k = 0; k < K; ++k) {
+        RecordArgs a = {};
+        a.dout = douts[k]; a.rec = recs[k]; a.N = N; a.C = C;
+        const int chunks = (C + 127) / 128;
+        a.CH = std::min(128, ((C + chunks - 1) / chunks + 3) & ~3);
+        const dim3 grid((N + 31) / 32, (C + a.CH - 1) / a.CH, B);
+        hipLaunchKernelGGL(corr_record_kernel, grid, dim3(256), (size_t)a.CH * 33 * sizeof(float), s, a);
+        const int rc = check_launch("corr_record_kernel");
+        if (rc) return rc;
+    }
+    return RAFTCORR_OK;
+}
+
+int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec, hipStream_t s)
+{
+    return launch_lookup_bwd_record_many(&dout, 1, B, N, C, &rec, s);
 }
 
 // d0[B * N][S0] = folded, scaled level-0 gradient of the recorded lookups (+= when accumulate); wgmax: per-workgroup

@@ -39,6 +39,7 @@ int launch_build_bwd(const float* f1, const float* f2, int B, int D, int H, int 
 size_t build_bwd_deferred_workspace_bytes(int B, int D, int H, int W);
 bool build_bwd_deferred_supported(int H, int W, int L, int r);
 int launch_lookup_bwd_record(const float* dout, int B, int N, int C, float* rec, hipStream_t s);
+int launch_lookup_bwd_record_many(const float* const* douts, int K, int B, int N, int C, float* const* recs, hipStream_t s);
 int launch_build_bwd_deferred(const float* f1, const float* f2, int B, int D, int H, int W, int L, int r, int mode,
                               int K, const float* const* coords, const float* const* records, const LevelSet* dlv,
                               float* df1, float* df2, void* workspace, size_t workspace_bytes, hipStream_t s);

@@ -834,6 +834,15 @@ def test_lookup_bwd_record_is_a_transposition(dev):
         rec = torch.full((B, H * W, C), float("nan"), device=dev)
         _lib.check(lib.raftcorr_lookup_bwd_record(x.data_ptr(), B, H, W, C, rec.data_ptr(), st), "lookup_bwd_record")
         assert torch.equal(rec, x.reshape(B, C, H * W).permute(0, 2, 1))
+        # raftcorr_lookup_bwd_record_many: several gradients in one call (more than one launch holds: 16), the same bits
+        K = 19 if C <= 324 and H * W < 1000 else 3
+        xs = [torch.randn(B, C, H, W, device=dev) for _ in range(K)]
+        recs = torch.full((K, B, H * W, C), float("nan"), device=dev)
+        _lib.check(lib.raftcorr_lookup_bwd_record_many(_lib.ptr_array(xs), K, B, H, W, C,
+                                                       _lib.ptr_array([recs[k] for k in range(K)]), st), "lookup_bwd_record_many")
+        for k in range(K):
+            assert torch.equal(recs[k], xs[k].reshape(B, C, H * W).permute(0, 2, 1)), k
+    assert lib.raftcorr_lookup_bwd_record_many(None, 1, 1, 4, 4, 4, None, st) != 0          # null arrays are refused
 
 
 def test_on_the_fly_backward_is_bit_reproducible(dev):
